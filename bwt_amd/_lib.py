@@ -1,0 +1,77 @@
+"""ctypes loader for libbwt_mi355x.so (the HIP kernels and their C-ABI).
+
+There is no CPU fallback: if the shared library is missing this module raises,
+and every compute call fails loudly when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbwt_mi355x.so")
+
+vp = C.c_void_p
+u64 = C.c_uint64
+u32 = C.c_uint32
+sz = C.c_size_t
+
+
+class BwtGpuError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/bwt_gpu.h one to one
+SIGNATURES = {
+    "bwtgpu_init": (C.c_int, [C.c_int]),
+    "bwtgpu_last_error": (C.c_char_p, []),
+    "bwtgpu_device_count": (C.c_int, []),
+    "bwtgpu_timing_enable": (C.c_int, [C.c_int]),
+    "bwtgpu_timing_reset": (C.c_int, []),
+    "bwtgpu_timing_get": (C.c_int, [C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]),
+    "bwtgpu_timing_report": (C.c_int, [C.c_char_p, sz]),
+    "bwtgpu_sa_workspace_bytes": (sz, [u32]),
+    "bwtgpu_sa_build": (C.c_int, [vp, u32, vp, vp, sz, vp]),
+    "bwtgpu_sa_last_stats": (C.c_int, [C.POINTER(u64)]),
+    "bwtgpu_bwt_from_sa": (C.c_int, [vp, vp, u32, vp, vp, vp]),
+    "bwtgpu_index_build": (vp, [vp, u32, vp]),
+    "bwtgpu_index_build_dev": (vp, [vp, u32, vp]),
+    "bwtgpu_index_from_parts": (vp, [vp, u32, u32, vp, vp]),
+    "bwtgpu_index_free": (None, [vp]),
+    "bwtgpu_index_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
+    "bwtgpu_index_export": (C.c_int, [vp, vp, vp]),
+    "bwtgpu_index_rank_rows16": (C.c_int, [vp, vp]),
+    "bwtgpu_index_device_bytes": (sz, [vp]),
+    "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
+    "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_locate_workspace_bytes": (sz, []),
+    "bwtgpu_locate_rows": (C.c_int, [vp, vp, u64, vp, vp, vp, sz, vp]),
+    "bwtgpu_gen_genome": (C.c_int, [vp, u64, u64, vp]),
+    "bwtgpu_gen_reads": (C.c_int, [vp, u64, vp, u64, u32, u64, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BwtGpuError(
+                f"{LIB_PATH} is missing: build it with `make` (hipcc, gfx950); "
+                "there is no CPU fallback"
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BwtGpuError(f"libbwt_mi355x error {rc}: {load().bwtgpu_last_error().decode()}")
+
+
+def last_error():
+    return load().bwtgpu_last_error().decode()

@@ -1,0 +1,120 @@
+// Shared host-side plumbing for the gfx950 kernels: error reporting, launch
+// timing, the HBM index object.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/bwt_gpu.h"
+
+namespace bwtgpu {
+
+enum : int {
+  kOk = 0,
+  kErrHip = -1,       // a HIP runtime call failed
+  kErrArg = -2,       // bad argument (null pointer, size out of range)
+  kErrWorkspace = -3, // workspace too small
+  kErrDevice = -4,    // no usable gfx950 device
+  kErrInternal = -5,  // invariant violated on device (reported, never ignored)
+};
+
+int set_error(int code, const char *fmt, ...);
+
+#define BWT_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t e__ = (expr);                                                 \
+    if (e__ != hipSuccess)                                                   \
+      return ::bwtgpu::set_error(::bwtgpu::kErrHip, "%s: %s (%s:%d)", #expr, \
+                                 hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+#define BWT_TRY(expr)           \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// Per-thread launch timing: when enabled, each launch goes through
+// ScopedKernelTimer which records two events on the launch stream; durations
+// are resolved lazily (after the stream has drained) by timing_get/report.
+struct TimingState {
+  bool enabled = false;
+  struct Pending {
+    std::string name;
+    hipEvent_t a, b;
+  };
+  std::vector<Pending> pending;
+  std::map<std::string, std::pair<uint64_t, double>> totals;
+};
+TimingState &timing();
+
+class ScopedKernelTimer {
+ public:
+  ScopedKernelTimer(const char *name, hipStream_t s);
+  ~ScopedKernelTimer();
+
+ private:
+  const char *name_;
+  hipStream_t s_;
+  hipEvent_t a_ = nullptr, b_ = nullptr;
+  bool on_ = false;
+};
+
+#define BWT_LAUNCH(name, kernel, grid, block, shmem, stream, ...)              \
+  do {                                                                         \
+    ::bwtgpu::ScopedKernelTimer t__(name, stream);                             \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);       \
+  } while (0)
+
+#define BWT_CHECK_LAUNCH()                                                     \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess)                                                     \
+      return ::bwtgpu::set_error(::bwtgpu::kErrHip, "kernel launch: %s (%s:%d)", \
+                                 hipGetErrorString(e__), __FILE__, __LINE__);  \
+  } while (0)
+
+// One 64-base block of the HBM index: 32 bytes, one sector per rank query.
+//   occ[c] = C[c] + number of c in BWT[0, 64*b)  (C folded in, so a backward
+//            search step is one add-free lookup)
+//   lo/hi  = bit-planes of the 64 bases of the block (bit k = base 64*b+k)
+struct __attribute__((aligned(32))) IndexBlock {
+  uint32_t occ[4];
+  uint64_t lo, hi;
+};
+static_assert(sizeof(IndexBlock) == 32, "one rank = one 32-byte sector");
+
+}  // namespace bwtgpu
+
+struct bwtgpu_index {
+  uint32_t n = 0;        // bases
+  uint32_t endloc = 0;   // row of the (unstored) $ in the BWT
+  uint32_t C[5] = {0, 0, 0, 0, 0};
+  uint64_t nblocks = 0;  // n/64 + 1
+  bwtgpu::IndexBlock *d_blocks = nullptr;
+  uint32_t *d_idxs = nullptr;  // 1 + n/32 sampled SA rows
+  int device = 0;
+};
+
+namespace bwtgpu {
+
+constexpr int kWave = 64;
+
+inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// index.hip
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
+int index_alloc(bwtgpu_index **out, uint32_t n);
+
+// sa_build.hip
+int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
+                  size_t ws_bytes, hipStream_t s);
+
+}  // namespace bwtgpu

@@ -1,0 +1,54 @@
+// Device-side FM-index primitives over the 32-byte block layout.
+#pragma once
+
+#include "common.hpp"
+
+namespace bwtgpu {
+
+// What a kernel needs of an index, passed by value (lives in SGPRs).
+struct IndexView {
+  const IndexBlock *blocks;
+  const uint32_t *idxs;
+  uint32_t n;
+  uint32_t endloc;
+};
+
+inline IndexView view_of(const bwtgpu_index *ix) {
+  return IndexView{ix->d_blocks, ix->d_idxs, ix->n, ix->endloc};
+}
+
+__device__ __forceinline__ uint64_t low_mask(uint32_t r) {
+  // r in [0, 63]
+  return (1ull << r) - 1ull;
+}
+
+// C[c] + Occ(c, idx) for a full-BWT row number idx in [0, n+1]: the value a
+// backward-search step assigns (seqindex.c:236-239 with rank, :221-225, and
+// seq_rank, :91-111).  nlo/nhi are the per-symbol plane inverters:
+// nlo = (c & 1) ? 0 : ~0, nhi = (c & 2) ? 0 : ~0.
+__device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
+                                          uint64_t nlo, uint64_t nhi, uint32_t idx) {
+  idx -= (idx > v.endloc);  // the $ row is not stored (seqindex.c:222-223)
+  const IndexBlock *b = v.blocks + (idx >> 6);
+  const uint32_t base = b->occ[c];
+  const uint64_t lo = b->lo, hi = b->hi;
+  const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(idx & 63u);
+  return base + (uint32_t)__popcll(match);
+}
+
+// LF mapping (seqindex.c:214-219) for a row in [0, n].
+__device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx) {
+  if (idx == v.endloc) return 0;
+  const uint32_t j = idx - (idx > v.endloc);
+  const IndexBlock *b = v.blocks + (j >> 6);
+  const uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
+  const uint64_t lo = b->lo, hi = b->hi;
+  const uint32_t r = j & 63u;
+  const uint32_t c = (uint32_t)((lo >> r) & 1ull) | ((uint32_t)((hi >> r) & 1ull) << 1);
+  const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+  const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(r);
+  const uint32_t base = c == 0 ? occ.x : c == 1 ? occ.y : c == 2 ? occ.z : occ.w;
+  return base + (uint32_t)__popcll(match);
+}
+
+}  // namespace bwtgpu

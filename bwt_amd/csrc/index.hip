@@ -1,0 +1,388 @@
+// FM-index object in HBM: rank blocks from a packed BWT (the rebuild that
+// read_index does on the host, fileio.c:62-63 -> seq_index, seqindex.c:23-87),
+// export of the stored parts, and the reference-layout rank rows.
+#include "common.hpp"
+#include "fm_device.hpp"
+
+namespace bwtgpu {
+
+constexpr int kTileThreads = 256;
+constexpr int kBlocksPerThread = 8;
+constexpr int kTileBlocks = kTileThreads * kBlocksPerThread;  // 2048 index blocks = 131072 bases
+
+// 16 bases of reference-packed BWT (4 bytes, first base in the top bits of the
+// first byte) -> 16 plane bits each.
+__device__ __forceinline__ void word_to_planes(uint32_t w, uint32_t &lo16, uint32_t &hi16) {
+  auto squeeze = [](uint32_t x) {
+    // x holds one bit per base at even positions; pack to a nibble per byte,
+    // reverse the nibble (base 0 of a byte sits in its top bits), then gather
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = ((x & 0x01010101u) << 3) | ((x & 0x02020202u) << 1) |
+        ((x & 0x04040404u) >> 1) | ((x & 0x08080808u) >> 3);
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+  };
+  lo16 = squeeze(w & 0x55555555u);
+  hi16 = squeeze((w >> 1) & 0x55555555u);
+}
+
+// One thread per index block: 16 bytes of packed BWT -> bit-planes.  d_bwt is
+// readable up to 16*nblocks bytes (the caller pads); bases >= n are cleared.
+__global__ void k_bwt_to_planes(const uint4 *__restrict__ d_bwt, IndexBlock *__restrict__ blocks,
+                                uint64_t nblocks, uint32_t n) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  uint4 w = d_bwt[b];
+  uint32_t l0, h0, l1, h1, l2, h2, l3, h3;
+  word_to_planes(w.x, l0, h0);
+  word_to_planes(w.y, l1, h1);
+  word_to_planes(w.z, l2, h2);
+  word_to_planes(w.w, l3, h3);
+  uint64_t lo = (uint64_t)l0 | ((uint64_t)l1 << 16) | ((uint64_t)l2 << 32) | ((uint64_t)l3 << 48);
+  uint64_t hi = (uint64_t)h0 | ((uint64_t)h1 << 16) | ((uint64_t)h2 << 32) | ((uint64_t)h3 << 48);
+  uint64_t first = b * 64;
+  uint64_t valid = first >= n ? 0 : (n - first >= 64 ? 64 : n - first);
+  uint64_t mask = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+  blocks[b].lo = lo & mask;
+  blocks[b].hi = hi & mask;
+}
+
+__device__ __forceinline__ void block_counts(const IndexBlock &blk, uint64_t b, uint32_t n,
+                                             uint32_t cnt[4]) {
+  uint64_t first = b * 64;
+  uint64_t valid = first >= n ? 0 : (n - first >= 64 ? 64 : n - first);
+  uint64_t mask = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+  uint64_t lo = blk.lo, hi = blk.hi;
+  cnt[0] = __popcll(~lo & ~hi & mask);
+  cnt[1] = __popcll(lo & ~hi & mask);
+  cnt[2] = __popcll(~lo & hi & mask);
+  cnt[3] = __popcll(lo & hi & mask);
+}
+
+// Pass 1 of the rank-table scan: per-tile totals of the four base counts.
+__global__ void __launch_bounds__(kTileThreads)
+k_rank_tile_reduce(const IndexBlock *__restrict__ blocks, uint64_t nblocks, uint32_t n,
+                   uint4 *__restrict__ tile_sums) {
+  __shared__ uint32_t s[4][kTileThreads / kWave];
+  uint64_t b0 = (uint64_t)blockIdx.x * kTileBlocks + (uint64_t)threadIdx.x * kBlocksPerThread;
+  uint32_t acc[4] = {0, 0, 0, 0};
+  for (int k = 0; k < kBlocksPerThread; ++k) {
+    uint64_t b = b0 + k;
+    if (b < nblocks) {
+      uint32_t c[4];
+      block_counts(blocks[b], b, n, c);
+      for (int q = 0; q < 4; ++q) acc[q] += c[q];
+    }
+  }
+  for (int q = 0; q < 4; ++q) {
+    uint32_t v = acc[q];
+    for (int off = 32; off; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s[q][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t[4];
+    for (int q = 0; q < 4; ++q) {
+      t[q] = 0;
+      for (int w = 0; w < kTileThreads / kWave; ++w) t[q] += s[q][w];
+    }
+    tile_sums[blockIdx.x] = make_uint4(t[0], t[1], t[2], t[3]);
+  }
+}
+
+// Pass 2: one workgroup turns tile totals into exclusive tile prefixes with
+// C[c] folded in, and publishes C[0..4] (seqindex.c:183-187).
+__global__ void __launch_bounds__(1024)
+k_rank_scan_tiles(uint4 *__restrict__ tile_sums, uint32_t ntiles, uint32_t *__restrict__ d_C) {
+  __shared__ uint32_t s[4][1024];
+  __shared__ uint32_t carry[4];
+  __shared__ uint32_t Cs[5];
+  const int t = threadIdx.x;
+  if (t < 4) carry[t] = 0;
+  __syncthreads();
+  // first sweep: grand totals, to know C before writing prefixes
+  uint32_t tot[4] = {0, 0, 0, 0};
+  for (uint32_t i = t; i < ntiles; i += 1024) {
+    uint4 v = tile_sums[i];
+    tot[0] += v.x; tot[1] += v.y; tot[2] += v.z; tot[3] += v.w;
+  }
+  for (int q = 0; q < 4; ++q) s[q][t] = tot[q];
+  __syncthreads();
+  for (int off = 512; off; off >>= 1) {
+    if (t < off)
+      for (int q = 0; q < 4; ++q) s[q][t] += s[q][t + off];
+    __syncthreads();
+  }
+  if (t == 0) {
+    Cs[0] = 1;
+    for (int q = 0; q < 4; ++q) Cs[q + 1] = Cs[q] + s[q][0];
+    for (int q = 0; q < 5; ++q) d_C[q] = Cs[q];
+  }
+  __syncthreads();
+  // second sweep: chunked exclusive scan with a running carry
+  for (uint32_t base = 0; base < ntiles; base += 1024) {
+    uint32_t i = base + t;
+    uint4 v = i < ntiles ? tile_sums[i] : make_uint4(0, 0, 0, 0);
+    uint32_t own[4] = {v.x, v.y, v.z, v.w};
+    for (int q = 0; q < 4; ++q) s[q][t] = own[q];
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint32_t add[4] = {0, 0, 0, 0};
+      if (t >= off)
+        for (int q = 0; q < 4; ++q) add[q] = s[q][t - off];
+      __syncthreads();
+      for (int q = 0; q < 4; ++q) s[q][t] += add[q];
+      __syncthreads();
+    }
+    if (i < ntiles) {
+      uint4 o;
+      o.x = Cs[0] + carry[0] + s[0][t] - own[0];
+      o.y = Cs[1] + carry[1] + s[1][t] - own[1];
+      o.z = Cs[2] + carry[2] + s[2][t] - own[2];
+      o.w = Cs[3] + carry[3] + s[3][t] - own[3];
+      tile_sums[i] = o;
+    }
+    __syncthreads();
+    if (t < 4) carry[t] += s[t][1023];
+    __syncthreads();
+  }
+}
+
+// Pass 3: exclusive scan inside each tile; writes occ[] of every block.
+__global__ void __launch_bounds__(kTileThreads)
+k_rank_apply(IndexBlock *__restrict__ blocks, uint64_t nblocks, uint32_t n,
+             const uint4 *__restrict__ tile_prefix) {
+  __shared__ uint32_t wsum[4][kTileThreads / kWave];
+  uint64_t b0 = (uint64_t)blockIdx.x * kTileBlocks + (uint64_t)threadIdx.x * kBlocksPerThread;
+  uint32_t cnt[kBlocksPerThread][4];
+  uint32_t acc[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < kBlocksPerThread; ++k) {
+    uint64_t b = b0 + k;
+    if (b < nblocks) {
+      block_counts(blocks[b], b, n, cnt[k]);
+    } else {
+      cnt[k][0] = cnt[k][1] = cnt[k][2] = cnt[k][3] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += cnt[k][q];
+  }
+  // exclusive scan of per-thread totals across the workgroup
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t excl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t v = acc[q];
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[q][wave] = v;
+    excl[q] = v - acc[q];
+  }
+  __syncthreads();
+  uint4 tp = tile_prefix[blockIdx.x];
+  uint32_t run[4] = {tp.x, tp.y, tp.z, tp.w};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    for (int w = 0; w < wave; ++w) run[q] += wsum[q][w];
+    run[q] += excl[q];
+  }
+#pragma unroll
+  for (int k = 0; k < kBlocksPerThread; ++k) {
+    uint64_t b = b0 + k;
+    if (b < nblocks) {
+      *reinterpret_cast<uint4 *>(blocks[b].occ) = make_uint4(run[0], run[1], run[2], run[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) run[q] += cnt[k][q];
+    }
+  }
+}
+
+// Bit-planes -> reference-packed BWT bytes, one thread per index block.
+__global__ void k_planes_to_bwt(const IndexBlock *__restrict__ blocks, uint64_t nblocks,
+                                uint4 *__restrict__ d_bwt) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  uint64_t lo = blocks[b].lo, hi = blocks[b].hi;
+  uint32_t w[4];
+  for (int q = 0; q < 4; ++q) {
+    uint32_t acc = 0;
+    for (int k = 0; k < 16; ++k) {
+      int bit = 16 * q + k;
+      uint32_t base = (uint32_t)((lo >> bit) & 1ull) | ((uint32_t)((hi >> bit) & 1ull) << 1);
+      int byte = k >> 2, slot = k & 3;
+      acc |= base << (8 * byte + 2 * (3 - slot));
+    }
+    w[q] = acc;
+  }
+  d_bwt[b] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Reference-layout rank rows (seqindex.c:23-87, blocksize 16): row j holds the
+// counts of each base in BWT[0, min(16 j, n)).
+__global__ void k_rank_rows16(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
+                              uint64_t rows, uint4 *__restrict__ out) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows) return;
+  uint64_t p = j * 16;
+  if (p > v.n) p = v.n;
+  const IndexBlock *b = v.blocks + (p >> 6);
+  uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
+  uint64_t lo = b->lo, hi = b->hi, m = low_mask((uint32_t)(p & 63));
+  uint4 r;
+  r.x = occ.x - C0 + __popcll(~lo & ~hi & m);
+  r.y = occ.y - C1 + __popcll(lo & ~hi & m);
+  r.z = occ.z - C2 + __popcll(~lo & hi & m);
+  r.w = occ.w - C3 + __popcll(lo & hi & m);
+  out[j] = r;
+}
+
+int index_alloc(bwtgpu_index **out, uint32_t n) {
+  if (n == 0 || n > 0xFFFFFFF0u)
+    return set_error(kErrArg, "text length %u out of range", n);
+  bwtgpu_index *ix = new bwtgpu_index();
+  ix->n = n;
+  ix->nblocks = (uint64_t)n / 64 + 1;
+  BWT_HIP(hipGetDevice(&ix->device));
+  hipError_t e = hipMalloc(&ix->d_blocks, ix->nblocks * sizeof(IndexBlock));
+  if (e == hipSuccess) e = hipMalloc(&ix->d_idxs, ((uint64_t)n / 32 + 1) * sizeof(uint32_t));
+  if (e != hipSuccess) {
+    bwtgpu_index_free(ix);
+    return set_error(kErrHip, "hipMalloc of index for n=%u failed: %s", n, hipGetErrorString(e));
+  }
+  *out = ix;
+  return kOk;
+}
+
+// Planes of every block are in place; computes occ[] and C[].
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
+  const uint64_t nb = ix->nblocks;
+  const uint32_t ntiles = (uint32_t)div_up(nb, kTileBlocks);
+  uint4 *d_tiles = nullptr;
+  uint32_t *d_C = nullptr;
+  BWT_HIP(hipMalloc(&d_tiles, (size_t)ntiles * sizeof(uint4) + 64));
+  d_C = reinterpret_cast<uint32_t *>(d_tiles + ntiles);
+  BWT_LAUNCH("rank_tile_reduce", k_rank_tile_reduce, dim3(ntiles), dim3(kTileThreads), 0, s,
+             ix->d_blocks, nb, ix->n, d_tiles);
+  BWT_LAUNCH("rank_scan_tiles", k_rank_scan_tiles, dim3(1), dim3(1024), 0, s, d_tiles, ntiles, d_C);
+  BWT_LAUNCH("rank_apply", k_rank_apply, dim3(ntiles), dim3(kTileThreads), 0, s, ix->d_blocks, nb,
+             ix->n, d_tiles);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_tiles);
+  if (e != hipSuccess) return set_error(kErrHip, "rank table build: %s", hipGetErrorString(e));
+  if (ix->C[4] != ix->n + 1)
+    return set_error(kErrInternal, "rank table totals %u != n+1 = %u", ix->C[4], ix->n + 1);
+  return kOk;
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+void bwtgpu_index_free(bwtgpu_index *ix) {
+  if (!ix) return;
+  if (ix->d_blocks) (void)hipFree(ix->d_blocks);
+  if (ix->d_idxs) (void)hipFree(ix->d_idxs);
+  delete ix;
+}
+
+bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t endloc,
+                                      const uint32_t *h_idxs, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h_bwt || !h_idxs) {
+    set_error(kErrArg, "null input");
+    return nullptr;
+  }
+  if (endloc > n) {
+    set_error(kErrArg, "endloc %u beyond n=%u", endloc, n);
+    return nullptr;
+  }
+  bwtgpu_index *ix = nullptr;
+  if (index_alloc(&ix, n) != kOk) return nullptr;
+  ix->endloc = endloc;
+  const uint64_t nb = ix->nblocks;
+  const size_t bwt_bytes = ((size_t)n + 3) / 4;
+  uint8_t *d_bwt = nullptr;
+  auto fail = [&](hipError_t e, const char *what) {
+    set_error(kErrHip, "%s: %s", what, hipGetErrorString(e));
+    if (d_bwt) (void)hipFree(d_bwt);
+    bwtgpu_index_free(ix);
+    return (bwtgpu_index *)nullptr;
+  };
+  hipError_t e = hipMalloc(&d_bwt, nb * 16);
+  if (e != hipSuccess) return fail(e, "hipMalloc bwt staging");
+  e = hipMemsetAsync(d_bwt, 0, nb * 16, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_bwt, h_bwt, bwt_bytes, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(ix->d_idxs, h_idxs, ((size_t)n / 32 + 1) * 4, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return fail(e, "index upload");
+  {
+    ScopedKernelTimer t("bwt_to_planes", s);
+    hipLaunchKernelGGL(k_bwt_to_planes, dim3((unsigned)div_up(nb, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4 *>(d_bwt), ix->d_blocks, nb, n);
+  }
+  int rc = index_finish_from_planes(ix, s);
+  (void)hipFree(d_bwt);
+  if (rc != kOk) {
+    bwtgpu_index_free(ix);
+    return nullptr;
+  }
+  return ix;
+}
+
+int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc, uint32_t C[5]) {
+  if (!ix) return set_error(kErrArg, "null index");
+  if (n) *n = ix->n;
+  if (endloc) *endloc = ix->endloc;
+  if (C)
+    for (int i = 0; i < 5; ++i) C[i] = ix->C[i];
+  return kOk;
+}
+
+size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
+  if (!ix) return 0;
+  return ix->nblocks * sizeof(IndexBlock) + ((size_t)ix->n / 32 + 1) * 4;
+}
+
+int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {
+  if (!ix) return set_error(kErrArg, "null index");
+  BWT_HIP(hipSetDevice(ix->device));
+  if (h_idxs)
+    BWT_HIP(hipMemcpy(h_idxs, ix->d_idxs, ((size_t)ix->n / 32 + 1) * 4, hipMemcpyDeviceToHost));
+  if (h_bwt) {
+    uint4 *d_bwt = nullptr;
+    BWT_HIP(hipMalloc(&d_bwt, ix->nblocks * 16));
+    BWT_LAUNCH("planes_to_bwt", k_planes_to_bwt, dim3((unsigned)div_up(ix->nblocks, 256)), dim3(256),
+               0, nullptr, ix->d_blocks, ix->nblocks, d_bwt);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+      e = hipMemcpy(h_bwt, d_bwt, ((size_t)ix->n + 3) / 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bwt);
+    if (e != hipSuccess) return set_error(kErrHip, "bwt export: %s", hipGetErrorString(e));
+  }
+  return kOk;
+}
+
+int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows) {
+  if (!ix || !h_rows) return set_error(kErrArg, "null argument");
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint64_t rows = 1 + ((uint64_t)ix->n + 15) / 16;
+  uint4 *d_rows = nullptr;
+  BWT_HIP(hipMalloc(&d_rows, rows * 16));
+  BWT_LAUNCH("rank_rows16", k_rank_rows16, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, nullptr,
+             view_of(ix), ix->C[0], ix->C[1], ix->C[2], ix->C[3], rows, d_rows);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(h_rows, d_rows, rows * 16, hipMemcpyDeviceToHost);
+  (void)hipFree(d_rows);
+  if (e != hipSuccess) return set_error(kErrHip, "rank rows export: %s", hipGetErrorString(e));
+  return kOk;
+}
+
+}  // extern "C"

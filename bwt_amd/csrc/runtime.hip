@@ -1,0 +1,125 @@
+// Library plumbing: device selection, error strings, per-launch timing.
+#include <cstring>
+
+#include "common.hpp"
+
+namespace bwtgpu {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+TimingState &timing() {
+  static thread_local TimingState t;
+  return t;
+}
+
+ScopedKernelTimer::ScopedKernelTimer(const char *name, hipStream_t s)
+    : name_(name), s_(s) {
+  on_ = timing().enabled;
+  if (!on_) return;
+  if (hipEventCreate(&a_) != hipSuccess || hipEventCreate(&b_) != hipSuccess) {
+    on_ = false;
+    return;
+  }
+  (void)hipEventRecord(a_, s_);
+}
+
+ScopedKernelTimer::~ScopedKernelTimer() {
+  if (!on_) return;
+  (void)hipEventRecord(b_, s_);
+  timing().pending.push_back({name_, a_, b_});
+}
+
+static void timing_resolve() {
+  TimingState &t = timing();
+  for (auto &p : t.pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess &&
+        hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      auto &e = t.totals[p.name];
+      e.first += 1;
+      e.second += ms;
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  t.pending.clear();
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+const char *bwtgpu_last_error(void) { return g_err; }
+
+int bwtgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int bwtgpu_init(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return set_error(kErrDevice, "no HIP device visible (%s)",
+                     e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n)
+    return set_error(kErrArg, "device %d out of range (have %d)", device, n);
+  BWT_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BWT_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(kErrDevice, "device %d is %s; this library is built for gfx950 only",
+                     device, prop.gcnArchName);
+  return kOk;
+}
+
+int bwtgpu_timing_enable(int on) {
+  timing().enabled = on != 0;
+  return kOk;
+}
+
+int bwtgpu_timing_reset(void) {
+  timing_resolve();
+  timing().totals.clear();
+  return kOk;
+}
+
+int bwtgpu_timing_get(const char *kernel, uint64_t *launches, double *total_ms) {
+  timing_resolve();
+  auto it = timing().totals.find(kernel);
+  uint64_t l = 0;
+  double ms = 0;
+  if (it != timing().totals.end()) {
+    l = it->second.first;
+    ms = it->second.second;
+  }
+  if (launches) *launches = l;
+  if (total_ms) *total_ms = ms;
+  return kOk;
+}
+
+int bwtgpu_timing_report(char *buf, size_t cap) {
+  timing_resolve();
+  size_t off = 0;
+  for (auto &kv : timing().totals) {
+    int w = snprintf(buf + off, off < cap ? cap - off : 0, "%s %llu %.6f\n",
+                     kv.first.c_str(), (unsigned long long)kv.second.first,
+                     kv.second.second);
+    if (w < 0 || off + (size_t)w >= cap) break;
+    off += (size_t)w;
+  }
+  return (int)off;
+}
+
+}  // extern "C"

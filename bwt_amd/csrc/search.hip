@@ -1,0 +1,234 @@
+// FM-index backward search and locate: one read per lane, index resident in HBM.
+//
+// Per read of m bases the search touches 2(m-1) index blocks (one 32-byte
+// sector each) and its own m/4 bytes of packed pattern; locate adds one block
+// per LF step.  Both kernels are bound by random 32-byte HBM/L2 reads.
+#include "common.hpp"
+#include "fm_device.hpp"
+
+namespace bwtgpu {
+
+constexpr int kPackThreads = 256;
+constexpr uint32_t kPackLdsBytes = 48 * 1024;
+
+// Reads arrive as the reference passes them: one base per byte, read r at
+// d_pats + r*stride (fmitest.c:60-63 uses stride 1, overlapping 12-mers).
+// They are repacked once to 2 bits per base, word-major (word w of read r at
+// packed[w*R + r], base k of the word at bits 2k), so the search kernel's
+// pattern loads are coalesced and cost m/4 bytes per read.
+__global__ void __launch_bounds__(kPackThreads)
+k_pack_reads(const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride, uint64_t R,
+             uint32_t *__restrict__ packed, uint32_t span_bytes, int use_lds) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint64_t r0 = (uint64_t)blockIdx.x * kPackThreads;
+  const uint64_t r = r0 + threadIdx.x;
+  const uint32_t words = (m + 15) / 16;
+  if (use_lds) {
+    const uint8_t *src = pats + r0 * stride;
+    // bytes of this workgroup's reads; clipped to the last read of the batch
+    uint64_t last = R - 1 < r0 + kPackThreads - 1 ? R - 1 : r0 + kPackThreads - 1;
+    uint32_t span = (uint32_t)((last - r0) * stride + m);
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
+    const uint8_t *asrc = src - mis;  // 16-byte aligned, still inside the allocation's first line
+    // the aligned window [asrc, asrc + mis + span) may start before pats; those
+    // bytes sit in the same 16-byte granule as pats[0], which hipMalloc'd or
+    // torch-allocated buffers own (256-byte aligned bases), so for interior
+    // workgroups they are simply earlier reads
+    const uint32_t total = mis + span;
+    const uint32_t vecs = total / 16;
+    for (uint32_t i = threadIdx.x; i < vecs; i += kPackThreads)
+      reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
+    for (uint32_t i = vecs * 16 + threadIdx.x; i < total; i += kPackThreads) lds[i] = asrc[i];
+    __syncthreads();
+    if (r >= R) return;
+    const uint8_t *mine = lds + mis + (uint32_t)(threadIdx.x * stride);
+    for (uint32_t w = 0; w < words; ++w) {
+      uint32_t acc = 0;
+      const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
+      for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
+      packed[(uint64_t)w * R + r] = acc;
+    }
+  } else {
+    if (r >= R) return;
+    const uint8_t *mine = pats + r * stride;
+    for (uint32_t w = 0; w < words; ++w) {
+      uint32_t acc = 0;
+      const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
+      for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
+      packed[(uint64_t)w * R + r] = acc;
+    }
+  }
+  (void)span_bytes;
+}
+
+struct CTable {
+  uint32_t c[5];
+};
+
+// Backward search (loc_search, seqindex.c:280-309), one read per lane.
+// d_locrow (optional) receives the row locate() would hand to unc_sa
+// (seqindex.c:265-276): sp unless the interval emptied before the last step.
+__global__ void __launch_bounds__(256)
+k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R, uint32_t m,
+         uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int i = (int)m - 1;
+  uint32_t word = packed[(uint64_t)(i >> 4) * R + r];
+  uint32_t c = (word >> (2 * (i & 15))) & 3u;
+  uint32_t sp = c == 0 ? C.c[0] : c == 1 ? C.c[1] : c == 2 ? C.c[2] : C.c[3];
+  uint32_t ep = c == 0 ? C.c[1] : c == 1 ? C.c[2] : c == 2 ? C.c[3] : C.c[4];
+  bool early = false;
+  for (i = (int)m - 2; i >= 0; --i) {
+    if ((i & 15) == 15) word = packed[(uint64_t)(i >> 4) * R + r];
+    if (ep <= sp) {  // seqindex.c:299-301
+      early = true;
+      break;
+    }
+    c = (word >> (2 * (i & 15))) & 3u;
+    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+    const uint32_t nsp = occ_c(v, c, nlo, nhi, sp);
+    const uint32_t nep = occ_c(v, c, nlo, nhi, ep);
+    sp = nsp;
+    ep = nep;
+  }
+  d_sp[r] = sp;
+  d_ep[r] = ep;
+  if (d_locrow) d_locrow[r] = (early || sp > v.n) ? 0xFFFFFFFFu : sp;
+}
+
+constexpr uint32_t kLocateBatch = 256;  // rows a wave takes from the queue at a time
+
+// unc_sa (seqindex.c:244-255) for a batch of rows.  The walk length is
+// geometric (a row is sampled when row % 32 == 0), so lanes do not run one row
+// each to the end: a lane that finishes takes the next row from its wave's
+// share of a global queue, which keeps all 64 lanes walking.
+__global__ void __launch_bounds__(256)
+k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *__restrict__ pos,
+         unsigned long long *__restrict__ steps_total, unsigned long long *__restrict__ queue_head) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t loc_lo = 0, loc_hi = 0;  // wave-uniform: rows this wave holds
+  bool exhausted = false;           // wave-uniform: the queue has run dry
+  bool active = false;
+  uint32_t idx = 0, steps = 0;
+  uint64_t mine = 0;
+  unsigned long long my_steps = 0;
+  for (;;) {
+    const uint64_t need = __ballot(!active);
+    if (need) {
+      if (loc_lo >= loc_hi && !exhausted) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(queue_head, (unsigned long long)kLocateBatch);
+        base = __shfl(base, 0, 64);
+        if (base >= R) {
+          exhausted = true;
+          loc_lo = loc_hi = 0;
+        } else {
+          loc_lo = base;
+          loc_hi = base + kLocateBatch < R ? base + kLocateBatch : R;
+        }
+      }
+      if (!active) {
+        const uint64_t cand = loc_lo + (uint64_t)__popcll(need & low_mask(lane));
+        if (cand < loc_hi) {
+          const uint32_t row = rows[cand];
+          if (row > v.n) {
+            pos[cand] = 0xFFFFFFFFu;
+          } else {
+            mine = cand;
+            idx = row;
+            steps = 0;
+            active = true;
+          }
+        }
+      }
+      const uint64_t taken = (uint64_t)__popcll(need);
+      loc_lo = loc_lo + taken < loc_hi ? loc_lo + taken : loc_hi;
+    }
+    if (!__any(active)) {
+      if (exhausted && loc_lo >= loc_hi) break;
+      continue;
+    }
+    if (active) {
+      if ((idx & 31u) == 0) {
+        uint64_t x = (uint64_t)v.idxs[idx >> 5] + steps;
+        if (x > v.n) x -= (uint64_t)v.n + 1;  // seqindex.c:252-253
+        pos[mine] = (uint32_t)x;
+        my_steps += steps;
+        active = false;
+      } else {
+        idx = lf_step(v, idx);
+        ++steps;
+      }
+    }
+  }
+  if (steps_total) {
+    for (int off = 32; off; off >>= 1) my_steps += __shfl_down(my_steps, off, 64);
+    if (lane == 0 && my_steps) atomicAdd(steps_total, my_steps);
+  }
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m) {
+  return align_up((size_t)((m + 15) / 16) * R * sizeof(uint32_t), 256) + 256;
+}
+
+int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+                  uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
+                  size_t ws_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !d_pats || !d_sp || !d_ep || !d_ws) return set_error(kErrArg, "null argument");
+  if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
+  if (R == 0) return kOk;
+  if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
+  if (ws_bytes < bwtgpu_search_workspace_bytes(R, m))
+    return set_error(kErrWorkspace, "search workspace %zu < %zu bytes", ws_bytes,
+                     bwtgpu_search_workspace_bytes(R, m));
+  if ((uintptr_t)d_ws & 255u) return set_error(kErrArg, "workspace must be 256-byte aligned");
+  uint32_t *packed = reinterpret_cast<uint32_t *>(d_ws);
+  const uint64_t groups = div_up(R, kPackThreads);
+  if (groups > 0x7FFFFFFFull) return set_error(kErrArg, "too many reads for one launch");
+  const uint64_t span = (uint64_t)(kPackThreads - 1) * stride + m + 16;
+  const int use_lds = span <= kPackLdsBytes;
+  BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),
+             use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed,
+             (uint32_t)(use_lds ? span : 0), use_lds);
+  BWT_CHECK_LAUNCH();
+  CTable C;
+  for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+  BWT_LAUNCH("fm_search", k_search, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
+             packed, R, m, d_sp, d_ep, d_locrow);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+size_t bwtgpu_locate_workspace_bytes(void) { return 256; }
+
+int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R, uint32_t *d_pos,
+                       unsigned long long *d_steps, void *d_ws, size_t ws_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !d_rows || !d_pos || !d_ws) return set_error(kErrArg, "null argument");
+  if (ws_bytes < bwtgpu_locate_workspace_bytes())
+    return set_error(kErrWorkspace, "locate workspace %zu < %zu bytes", ws_bytes,
+                     bwtgpu_locate_workspace_bytes());
+  if ((uintptr_t)d_ws & 7u) return set_error(kErrArg, "workspace must be 8-byte aligned");
+  if (R == 0) return kOk;
+  unsigned long long *head = reinterpret_cast<unsigned long long *>(d_ws);
+  BWT_HIP(hipMemsetAsync(head, 0, 256, s));
+  // enough waves to fill the chip (256 CUs x 8 waves/SIMD x 4 SIMDs), no more
+  // than there are batches of rows
+  uint64_t waves = div_up(R, kLocateBatch);
+  uint64_t groups = div_up(waves, 4);
+  if (groups > 256 * 8) groups = 256 * 8;
+  BWT_LAUNCH("fm_locate", k_locate, dim3((unsigned)groups), dim3(256), 0, s, view_of(ix), d_rows, R,
+             d_pos, d_steps, head);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+"""Thin Python plumbing over the C-ABI: torch owns device memory and streams,
+libbwt_mi355x.so does the work.  Used by the tests and bench.py; the drop-in
+boundary for C callers is the shared library itself (include/*.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BwtGpuError, check
+
+NONE_ROW = 0xFFFFFFFF
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def init(device=0):
+    lib = _lib.load()
+    check(lib.bwtgpu_init(int(device)))
+    torch.cuda.set_device(int(device))
+    return lib
+
+
+def _as_u32(t):
+    """torch has no uint32 arithmetic; device rows are carried as int32 bits."""
+    return t.view(torch.int32) if t.dtype != torch.int32 else t
+
+
+def to_numpy_u32(t):
+    return t.detach().cpu().numpy().view(np.uint32)
+
+
+def timing_enable(on=True):
+    check(_lib.load().bwtgpu_timing_enable(1 if on else 0))
+
+
+def timing_reset():
+    check(_lib.load().bwtgpu_timing_reset())
+
+
+def timing_get(name):
+    n = C.c_uint64()
+    ms = C.c_double()
+    check(_lib.load().bwtgpu_timing_get(name.encode(), C.byref(n), C.byref(ms)))
+    return int(n.value), float(ms.value)
+
+
+def timing_report():
+    buf = C.create_string_buffer(1 << 16)
+    k = _lib.load().bwtgpu_timing_report(buf, len(buf))
+    out = {}
+    for line in buf.raw[:k].decode().splitlines():
+        name, launches, ms = line.split()
+        out[name] = (int(launches), float(ms))
+    return out
+
+
+class GpuIndex:
+    """Owning handle of an HBM-resident FM-index (bwtgpu_index*)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise BwtGpuError("index construction failed: " + _lib.last_error())
+        self.h = C.c_void_p(handle)
+        n, e = C.c_uint32(), C.c_uint32()
+        Cs = (C.c_uint32 * 5)()
+        check(_lib.load().bwtgpu_index_info(self.h, C.byref(n), C.byref(e), Cs))
+        self.n, self.endloc, self.C = int(n.value), int(e.value), [int(x) for x in Cs]
+        self._ws = None
+        self._lws = None
+
+    def close(self):
+        if self.h:
+            _lib.load().bwtgpu_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self):
+        return int(_lib.load().bwtgpu_index_device_bytes(self.h))
+
+    def export(self):
+        """(bwt bytes, idxs) in the reference's stored layout (fileio.c:14-15)."""
+        bwt = np.zeros((self.n + 3) // 4, np.uint8)
+        idxs = np.zeros(1 + self.n // 32, np.uint32)
+        check(_lib.load().bwtgpu_index_export(self.h, bwt.ctypes.data_as(C.c_void_p),
+                                              idxs.ctypes.data_as(C.c_void_p)))
+        return bwt, idxs
+
+    def rank_rows16(self):
+        rows = 1 + (self.n + 15) // 16
+        out = np.zeros((rows, 4), np.uint32)
+        check(_lib.load().bwtgpu_index_rank_rows16(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def _workspace(self, nbytes):
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        return self._ws
+
+    def search(self, d_pats, m, R, stride=None, want_locrow=False, out=None):
+        """d_pats: uint8 CUDA tensor, read r at offset r*stride (default m).
+        Returns (sp, ep[, locrow]) as int32 CUDA tensors holding uint32 bits."""
+        lib = _lib.load()
+        stride = m if stride is None else stride
+        need = (R - 1) * stride + m if R else 0
+        if d_pats.numel() < need:
+            raise ValueError(f"pattern buffer holds {d_pats.numel()} bytes, needs {need}")
+        if out is None:
+            sp = torch.empty(R, dtype=torch.int32, device="cuda")
+            ep = torch.empty(R, dtype=torch.int32, device="cuda")
+            lr = torch.empty(R, dtype=torch.int32, device="cuda") if want_locrow else None
+        else:
+            sp, ep, lr = out
+        wsb = int(lib.bwtgpu_search_workspace_bytes(R, m))
+        ws = self._workspace(wsb)
+        check(lib.bwtgpu_search(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(lr),
+                                _ptr(ws), ws.numel(), _stream()))
+        return (sp, ep, lr) if want_locrow else (sp, ep)
+
+    def locate_rows(self, d_rows, count_steps=False, out=None):
+        lib = _lib.load()
+        R = d_rows.numel()
+        pos = torch.empty(R, dtype=torch.int32, device="cuda") if out is None else out
+        steps = torch.zeros(1, dtype=torch.int64, device="cuda") if count_steps else None
+        if self._lws is None:
+            self._lws = torch.empty(int(lib.bwtgpu_locate_workspace_bytes()), dtype=torch.uint8,
+                                    device="cuda")
+        check(lib.bwtgpu_locate_rows(self.h, _ptr(d_rows), R, _ptr(pos), _ptr(steps),
+                                     _ptr(self._lws), self._lws.numel(), _stream()))
+        if count_steps:
+            return pos, int(steps.item())
+        return pos
+
+
+def index_from_parts(bwt, n, endloc, idxs):
+    """Stored parts of an index (numpy, host) -> HBM index; the device-side
+    counterpart of read_index's rebuild (fileio.c:62-63)."""
+    bwt = np.ascontiguousarray(bwt, np.uint8)
+    idxs = np.ascontiguousarray(idxs, np.uint32)
+    assert len(bwt) >= (n + 3) // 4 and len(idxs) >= 1 + n // 32
+    h = _lib.load().bwtgpu_index_from_parts(bwt.ctypes.data_as(C.c_void_p), n, endloc,
+                                            idxs.ctypes.data_as(C.c_void_p), _stream())
+    return GpuIndex(h)
+
+
+def build_index(text, n):
+    """make_fmi (seqindex.c:161-189) from a packed text on the host."""
+    text = np.ascontiguousarray(text, np.uint8)
+    assert len(text) >= n // 4 + 1
+    return GpuIndex(_lib.load().bwtgpu_index_build(text.ctypes.data_as(C.c_void_p), n, _stream()))
+
+
+def build_index_dev(d_text, n):
+    assert d_text.numel() >= n // 4 + 1
+    return GpuIndex(_lib.load().bwtgpu_index_build_dev(_ptr(d_text), n, _stream()))
+
+
+def sa_build(d_text, n, ws=None):
+    """histsort / csuff_arr on device: returns the n+1 SA rows (int32 bits)."""
+    lib = _lib.load()
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    wsb = int(lib.bwtgpu_sa_workspace_bytes(n))
+    if ws is None or ws.numel() < wsb:
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    check(lib.bwtgpu_sa_build(_ptr(d_text), n, _ptr(sa), _ptr(ws), ws.numel(), _stream()))
+    return sa
+
+
+def sa_last_stats():
+    st = (C.c_uint64 * 8)()
+    check(_lib.load().bwtgpu_sa_last_stats(st))
+    return [int(x) for x in st]
+
+
+def bwt_from_sa(d_text, d_sa, n):
+    lib = _lib.load()
+    nb = (n + 3) // 4
+    bwt = torch.zeros((nb + 15) // 16 * 16 + 16, dtype=torch.uint8, device="cuda")
+    endloc = torch.zeros(1, dtype=torch.int32, device="cuda")
+    check(lib.bwtgpu_bwt_from_sa(_ptr(d_text), _ptr(d_sa), n, _ptr(bwt), _ptr(endloc), _stream()))
+    return bwt[:nb], int(endloc.item()) & 0xFFFFFFFF
+
+
+def gen_genome(n, seed):
+    lib = _lib.load()
+    # padded so kernels may read whole 16-byte vectors past the last base
+    t = torch.zeros(n // 4 + 1 + 64, dtype=torch.uint8, device="cuda")
+    check(lib.bwtgpu_gen_genome(_ptr(t), n, seed, _stream()))
+    return t
+
+
+def gen_reads(d_text, n, R, m, seed, want_offsets=True):
+    lib = _lib.load()
+    reads = torch.empty(R * m + 64, dtype=torch.uint8, device="cuda")
+    offs = torch.empty(R, dtype=torch.int32, device="cuda") if want_offsets else None
+    check(lib.bwtgpu_gen_reads(_ptr(d_text), n, _ptr(reads), R, m, seed, _ptr(offs), _stream()))
+    return reads, offs

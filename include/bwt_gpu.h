@@ -1,0 +1,120 @@
+/*
+ * bwt_gpu.h -- device-level C-ABI of libbwt_mi355x.so (MI355X / gfx950).
+ *
+ * Plain C linkage, plain pointers and sizes.  Pointers whose name starts with
+ * d_ are device pointers (HBM), h_ host pointers.  `stream` is a hipStream_t
+ * passed as void* (NULL = the default stream).  Every function returns 0 on
+ * success and a negative code on failure; bwtgpu_last_error() returns the
+ * message for the calling thread.  Nothing here falls back to the CPU: if no
+ * gfx950 device is usable the call fails.
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * the yichizhng/bwt tree).  The reference runs these loops on the host; the
+ * batch forms exist because fmitest.c:54-91 and search_reads.c:102-162 loop
+ * over reads on the host and that loop is what moves to the GPU.
+ */
+#ifndef BWT_GPU_H
+#define BWT_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bwtgpu_index bwtgpu_index; /* HBM-resident FM-index */
+
+/* ---- library ---- */
+/* Makes `device` current for the calling thread and checks that it is a
+ * gfx950 part.  Must precede any other call on a thread. */
+int bwtgpu_init(int device);
+const char *bwtgpu_last_error(void);
+int bwtgpu_device_count(void);
+/* When enabled, every kernel launch of the calling thread's next calls is
+ * bracketed by HIP events on its own stream; bwtgpu_timing_get returns, for a
+ * kernel name, the number of launches and their summed duration since the
+ * last bwtgpu_timing_reset.  Used by bench.py for the roofline figures. */
+int bwtgpu_timing_enable(int on);
+int bwtgpu_timing_reset(void);
+int bwtgpu_timing_get(const char *kernel, uint64_t *launches, double *total_ms);
+/* fills buf with "name launches total_ms\n" lines; returns bytes written */
+int bwtgpu_timing_report(char *buf, size_t cap);
+
+/* ---- suffix array + BWT (HP1) ---- */
+/* Replaces histsort (histsortcomp.c:161-180) and csuff_arr (csacak.c:521-528):
+ * the suffix array of text+$ as n+1 uint32 rows, d_sa[0] = n.  d_text is the
+ * 2-bit packed text (base i in byte i>>2, bits 2*(3-(i&3)); histsortcomp.c:20-23),
+ * n/4+1 bytes readable; bits past base n-1 are ignored.  Repetitive inputs
+ * take the prefix-doubling path instead of overflowing a stack.
+ * Workspace: bwtgpu_sa_workspace_bytes(n) bytes at d_ws (256-B aligned). */
+size_t bwtgpu_sa_workspace_bytes(uint32_t n);
+int bwtgpu_sa_build(const uint8_t *d_text, uint32_t n, uint32_t *d_sa,
+                    void *d_ws, size_t ws_bytes, void *stream);
+/* counters of the last bwtgpu_sa_build on this thread (for tests/bench):
+ * [0] partition levels run, [1] leaf buckets, [2] rows left unresolved after
+ * the bucket phase, [3] prefix-doubling rounds, [4] deepest partition depth */
+int bwtgpu_sa_last_stats(uint64_t stats[8]);
+
+/* Replaces sprintcbwt (histsortcomp.c:220-250): packed BWT without the $ row
+ * ((n+3)/4 bytes at d_bwt) and the $ row number at *d_endloc. */
+int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n,
+                       uint8_t *d_bwt, uint32_t *d_endloc, void *stream);
+
+/* ---- FM-index build (HP1 tail) ---- */
+/* Replaces make_fmi / make_fmi_sacak (seqindex.c:161-212): SA build, every
+ * 32nd SA row (seqindex.c:173-176), BWT, rank blocks, C[].  h_text is the
+ * packed text on the host (n/4+1 bytes).  The SA never leaves the device. */
+bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream);
+/* Same from a packed text already in HBM. */
+bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream);
+/* Replaces the rebuild half of read_index (fileio.c:44-63): takes the stored
+ * parts of an index (host pointers) and rebuilds the rank blocks on device. */
+bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n,
+                                      uint32_t endloc, const uint32_t *h_idxs,
+                                      void *stream);
+void bwtgpu_index_free(bwtgpu_index *ix);
+/* The fields of fm_index (seqindex.h:14-22) that write_index stores
+ * (fileio.c:11-15).  Any output pointer may be NULL. */
+int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc,
+                      uint32_t C[5]);
+int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs);
+/* Rank rows in the reference's layout (seq_index, seqindex.c:23-87, blocksize
+ * 16): 1+(n+15)/16 rows of 4 counts, computed on device, copied to h_rows. */
+int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows);
+size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
+
+/* ---- backward search (HP2) ---- */
+/* Replaces the host loop over loc_search (seqindex.c:280-309; the worker loop
+ * fmitest.c:54-65): read r is the m bytes at d_pats + r*stride, one base
+ * (0..3) per byte as the reference passes them; d_sp[r], d_ep[r] are the
+ * half-open SA interval exactly as loc_search leaves them, including the
+ * sp >= ep values of a read that stops matching.  If d_locrow is not NULL it
+ * receives, per read, the row locate() (seqindex.c:258-277) would pass to
+ * unc_sa: sp, or 0xFFFFFFFF where locate() returns -1 (interval empty before
+ * the last step) or where sp = n+1 (the reference reads out of bounds there).
+ * Only the low two bits of a pattern byte are used.
+ * Workspace: bwtgpu_search_workspace_bytes(R, m) bytes, 256-byte aligned. */
+size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m);
+int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
+                  uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
+                  uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
+/* Replaces the host loop over unc_sa (seqindex.c:244-255): d_pos[r] =
+ * SA[d_rows[r]]; rows equal to 0xFFFFFFFF, or beyond n, give 0xFFFFFFFF.
+ * If d_steps is not NULL the total number of LF steps taken is ADDED to it
+ * (zero it first).  Workspace: bwtgpu_locate_workspace_bytes() bytes. */
+size_t bwtgpu_locate_workspace_bytes(void);
+int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R,
+                       uint32_t *d_pos, unsigned long long *d_steps,
+                       void *d_ws, size_t ws_bytes, void *stream);
+/* ---- seeded synthetic inputs, generated in HBM (bench/test plumbing) ---- */
+/* Bit-identical to the host generators in bwt_amd/synth.py. */
+int bwtgpu_gen_genome(uint8_t *d_text, uint64_t n, uint64_t seed, void *stream);
+int bwtgpu_gen_reads(const uint8_t *d_text, uint64_t n, uint8_t *d_reads,
+                     uint64_t R, uint32_t m, uint64_t seed, uint32_t *d_offsets,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,145 @@
+"""HP2 parity on the GPU: rank blocks, backward search and locate through the
+C-ABI against the CPU oracle on the same seeded inputs (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from bwt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _index_pair(oracle, gpu, n, seed=synth.GENOME_SEED, text=None):
+    if text is None:
+        text = oracle.gen_genome(n, seed)
+    fo = oracle.make_fmi(text, n)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    return text, fo, ix
+
+
+@pytest.mark.parametrize("n", [1, 5, 13, 63, 64, 65, 777, 4096, 100003, 1000000])
+def test_rank_blocks_match_seq_index(oracle, gpu, n):
+    """Device rank blocks (from stored BWT, as read_index rebuilds them) give
+    the reference's rank rows (seqindex.c:23-87) and C[] (seqindex.c:183-187)."""
+    _, fo, ix = _index_pair(oracle, gpu, n)
+    assert ix.n == n and ix.endloc == fo.endloc
+    assert ix.C == fo.C
+    np.testing.assert_array_equal(ix.rank_rows16(), fo.rank_rows)
+    bwt, idxs = ix.export()
+    np.testing.assert_array_equal(bwt, fo.bwt)
+    np.testing.assert_array_equal(idxs, fo.idxs)
+
+
+@pytest.mark.parametrize("n,R,m", [(777, 500, 12), (100003, 5000, 20), (1000000, 10000, 20),
+                                   (1000000, 20000, 50), (1000000, 3000, 100), (1000000, 1000, 17)])
+def test_search_matches_loc_search(oracle, gpu, n, R, m):
+    text, fo, ix = _index_pair(oracle, gpu, n)
+    reads, offs = oracle.gen_reads(text, n, R, m, synth.READS_SEED)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    d = torch.from_numpy(reads.reshape(-1)).cuda()
+    sp, ep, lr = ix.search(d, m, R, want_locrow=True)
+    sp, ep, lr = (gpu.to_numpy_u32(x) for x in (sp, ep, lr))
+    np.testing.assert_array_equal(sp, sp_o)
+    np.testing.assert_array_equal(ep, ep_o)
+    # locate(): unc_sa(sp) unless the interval emptied before the last step
+    want = np.array([oracle.locate(fo, reads[r]) for r in range(min(R, 2000))], np.int64)
+    pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))
+    got = pos[: len(want)].astype(np.int64)
+    got[got == 0xFFFFFFFF] = -1
+    np.testing.assert_array_equal(got, want)
+    # reads sampled from the text locate to their own offset when unique
+    uniq = (ep - sp == 1) & (offs != 0xFFFFFFFF)
+    assert uniq.sum() > 0.9 * R * 0.5
+    np.testing.assert_array_equal(pos[uniq], offs[uniq])
+
+
+def test_search_overlapping_stride1(oracle, gpu):
+    """fmitest's workload shape: overlapping 12-mers pats+i (fmitest.c:60-63)."""
+    n, R, m = 100003, 20000, 12
+    text, fo, ix = _index_pair(oracle, gpu, n)
+    pats = (synth.rnd(7, np.arange(R + m, dtype=np.uint64)) & np.uint64(3)).astype(np.uint8)
+    sp_o, ep_o = oracle.search_batch(fo, pats, m, 1, R)
+    sp, ep = ix.search(torch.from_numpy(pats).cuda(), m, R, stride=1)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+    # reverse_search's return value (seqindex.c:228-242) follows from the interval
+    for r in range(0, R, 997):
+        rs = oracle.reverse_search(fo, pats[r:r + m])
+        sp_r, ep_r = int(sp_o[r]), int(ep_o[r])
+        assert rs in (0, ep_r - sp_r + 1)
+
+
+def test_search_wide_stride_and_unaligned_base(oracle, gpu):
+    n, R, m, stride = 100003, 3000, 33, 301
+    text, fo, ix = _index_pair(oracle, gpu, n)
+    reads, _ = oracle.gen_reads(text, n, R, m, 99)
+    buf = np.full(3 + R * stride + m, 7, np.uint8)  # junk between reads
+    for r in range(R):
+        buf[3 + r * stride: 3 + r * stride + m] = reads[r]
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    d = torch.from_numpy(buf).cuda()
+    sp, ep = ix.search(d[3:], m, R, stride=stride)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+    # narrow stride, unaligned base: LDS staging path
+    buf2 = np.zeros(5 + R * m, np.uint8)
+    buf2[5:] = reads.reshape(-1)
+    sp, ep = ix.search(torch.from_numpy(buf2).cuda()[5:], m, R)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+
+
+@pytest.mark.parametrize("n", [13, 777, 100003, 1000000])
+def test_locate_every_row_is_the_suffix_array(oracle, gpu, n):
+    """unc_sa(i) == SA[i] for every row (seqindex.c:244-255)."""
+    text = oracle.gen_genome(n, synth.GENOME_SEED)
+    sa = oracle.histsort(text, n)
+    fo = oracle.make_fmi(text, n, sa)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
+    pos, steps = ix.locate_rows(rows, count_steps=True)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(pos), sa)
+    _, steps_o = oracle.locate_rows(fo, np.arange(n + 1, dtype=np.uint32))
+    assert steps == steps_o
+
+
+def test_locate_skips_invalid_rows(oracle, gpu):
+    n = 4096
+    _, fo, ix = _index_pair(oracle, gpu, n)
+    rows = np.array([0, 0xFFFFFFFF, 5, n, n + 1, 0xFFFFFFFE, 77], np.uint32)
+    pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(rows.view(np.int32)).cuda()))
+    for r, p in zip(rows, pos):
+        if r > n:
+            assert p == 0xFFFFFFFF
+        else:
+            assert p == oracle.unc_sa(fo, int(r))
+
+
+def test_tandem_repeat_index(oracle, gpu):
+    """Highly repetitive text: wide SA intervals, long equal runs in the BWT."""
+    n = 200000
+    text = oracle.gen_tandem(n, 7, 11)
+    sa = oracle.sa_doubling(text, n)
+    fo = oracle.make_fmi(text, n, sa)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    np.testing.assert_array_equal(ix.rank_rows16(), fo.rank_rows)
+    reads, _ = oracle.gen_reads(text, n, 4000, 30, 5)
+    sp_o, ep_o = oracle.search_batch(fo, reads, 30, 30, 4000)
+    sp, ep = ix.search(torch.from_numpy(reads.reshape(-1)).cuda(), 30, 4000)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+    rows = torch.arange(0, n + 1, 3, dtype=torch.int64, device="cuda").to(torch.int32)
+    pos = gpu.to_numpy_u32(ix.locate_rows(rows))
+    np.testing.assert_array_equal(pos, sa[::3])
+
+
+def test_device_generators_match_host(oracle, gpu):
+    n, R, m = 100003, 5000, 50
+    t = gpu.gen_genome(n, synth.GENOME_SEED)
+    host = oracle.gen_genome(n, synth.GENOME_SEED)
+    np.testing.assert_array_equal(t[: n // 4 + 1].cpu().numpy(), host)
+    np.testing.assert_array_equal(synth.gen_genome(n), host)
+    reads, offs = gpu.gen_reads(t, n, R, m, synth.READS_SEED)
+    r_o, o_o = oracle.gen_reads(host, n, R, m, synth.READS_SEED)
+    np.testing.assert_array_equal(reads[: R * m].cpu().numpy().reshape(R, m), r_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(offs), o_o)
