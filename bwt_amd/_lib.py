@@ -46,6 +46,8 @@ SIGNATURES = {
     "bwtgpu_locate_rows": (C.c_int, [vp, vp, u64, vp, vp, vp, sz, vp]),
     "bwtgpu_gen_genome": (C.c_int, [vp, u64, u64, vp]),
     "bwtgpu_gen_reads": (C.c_int, [vp, u64, vp, u64, u32, u64, vp, vp]),
+    "bwtgpu_diag_scan": (C.c_int, [C.c_int, vp, vp, u64, vp, vp]),
+    "bwtgpu_diag_radix_sort": (C.c_int, [vp, vp, u64, C.c_int, vp]),
 }
 
 _lib = None

@@ -1,0 +1,172 @@
+// FM-index build on device (make_fmi, seqindex.c:161-189): suffix array, BWT
+// (sprintcbwt, histsortcomp.c:220-250), every 32nd SA row (seqindex.c:173-176),
+// rank blocks and C[] (seq_index, seqindex.c:23-87, :183-187).  The suffix
+// array stays in HBM; only what write_index stores ever goes to the host.
+#include "common.hpp"
+#include "fm_device.hpp"
+
+namespace bwtgpu {
+
+__device__ __forceinline__ uint32_t text_base(const uint8_t *__restrict__ t, uint64_t i) {
+  return (t[i >> 2] >> (2 * (3 - (i & 3)))) & 3u;  // histsortcomp.c:20-23
+}
+
+// The row whose suffix starts at 0 has no preceding base: that is the $ of
+// the BWT (histsortcomp.c:232-236).
+__global__ void k_find_endloc(const uint32_t *__restrict__ sa, uint64_t rows,
+                              uint32_t *__restrict__ endloc) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < rows && sa[j] == 0) *endloc = (uint32_t)j;
+}
+
+// One wave emits one 64-base block: lane k holds BWT position 64*b + k, whose
+// SA row is one further along once past the $ row (histsortcomp.c:238-245);
+// the two ballots are the block's bit-planes.
+__global__ void __launch_bounds__(256)
+k_emit_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa, uint32_t n,
+              const uint32_t *__restrict__ d_endloc, IndexBlock *__restrict__ blocks,
+              uint64_t nblocks) {
+  const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (b >= nblocks) return;  // wave-uniform
+  const uint32_t endloc = *d_endloc;
+  const uint64_t p = b * 64 + lane;
+  uint32_t base = 0;
+  if (p < n) {
+    const uint64_t row = p + (p >= endloc ? 1 : 0);
+    base = text_base(text, (uint64_t)sa[row] - 1);
+  }
+  const uint64_t lo = __ballot(base & 1u);
+  const uint64_t hi = __ballot(base & 2u);
+  if (lane == 0) {
+    blocks[b].lo = lo;
+    blocks[b].hi = hi;
+  }
+}
+
+__global__ void k_sample_sa(const uint32_t *__restrict__ sa, uint64_t nsamples,
+                            uint32_t *__restrict__ idxs) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsamples) idxs[i] = sa[32 * i];
+}
+
+// sprintcbwt's own output format: four bases per byte, first base in the top
+// bits, $ row skipped, zero padding in the last byte.  One thread per byte.
+__global__ void k_emit_bwt_bytes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa,
+                                 uint32_t n, const uint32_t *__restrict__ d_endloc,
+                                 uint8_t *__restrict__ bwt) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ((uint64_t)n + 3) / 4) return;
+  const uint32_t endloc = *d_endloc;
+  uint32_t acc = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t p = 4 * q + k;
+    if (p < n) {
+      const uint64_t row = p + (p >= endloc ? 1 : 0);
+      acc |= text_base(text, (uint64_t)sa[row] - 1) << (2 * (3 - k));
+    }
+  }
+  bwt[q] = (uint8_t)acc;
+}
+
+static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t s,
+                                  bwtgpu_index **out) {
+  bwtgpu_index *ix = nullptr;
+  BWT_TRY(index_alloc(&ix, n));
+  const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
+  uint32_t *d_sa = nullptr;
+  void *d_ws = nullptr;
+  uint32_t *d_endloc = nullptr;
+  int rc = kOk;
+  auto cleanup = [&]() {
+    if (d_sa) (void)hipFree(d_sa);
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_endloc) (void)hipFree(d_endloc);
+  };
+  hipError_t e = hipMalloc(&d_sa, ((size_t)n + 1) * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_ws, ws_bytes);
+  if (e == hipSuccess) e = hipMalloc(&d_endloc, 256);
+  if (e != hipSuccess) {
+    cleanup();
+    bwtgpu_index_free(ix);
+    return set_error(kErrHip, "index build buffers for n=%u: %s", n, hipGetErrorString(e));
+  }
+  rc = sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, s);
+  if (rc == kOk) {
+    const uint64_t rows = (uint64_t)n + 1;
+    (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
+    BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa,
+               rows, d_endloc);
+    BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0,
+               s, d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
+    const uint64_t ns = (uint64_t)n / 32 + 1;
+    BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns,
+               ix->d_idxs);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) rc = set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
+  }
+  if (rc == kOk) rc = index_finish_from_planes(ix, s);  // synchronises the stream
+  if (rc == kOk && ix->endloc > n) rc = set_error(kErrInternal, "no suffix-array row holds suffix 0");
+  cleanup();
+  if (rc != kOk) {
+    bwtgpu_index_free(ix);
+    return rc;
+  }
+  *out = ix;
+  return kOk;
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, uint8_t *d_bwt,
+                       uint32_t *d_endloc, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_text || !d_sa || !d_bwt || !d_endloc || n == 0) return set_error(kErrArg, "bad argument");
+  const uint64_t rows = (uint64_t)n + 1;
+  BWT_HIP(hipMemsetAsync(d_endloc, 0xFF, 4, s));
+  BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows,
+             d_endloc);
+  BWT_LAUNCH("emit_bwt_bytes", k_emit_bwt_bytes, dim3((unsigned)div_up(((uint64_t)n + 3) / 4, 256)),
+             dim3(256), 0, s, d_text, d_sa, n, d_endloc, d_bwt);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream) {
+  if (!d_text) {
+    set_error(kErrArg, "null text");
+    return nullptr;
+  }
+  bwtgpu_index *ix = nullptr;
+  if (build_from_device_text(d_text, n, (hipStream_t)stream, &ix) != kOk) return nullptr;
+  return ix;
+}
+
+bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!h_text || n == 0) {
+    set_error(kErrArg, "bad text");
+    return nullptr;
+  }
+  const size_t nbytes = (size_t)n / 4 + 1;
+  uint8_t *d_text = nullptr;
+  hipError_t e = hipMalloc(&d_text, nbytes + 64);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_text, h_text, nbytes, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) {
+    if (d_text) (void)hipFree(d_text);
+    set_error(kErrHip, "text upload: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  bwtgpu_index *ix = nullptr;
+  int rc = build_from_device_text(d_text, n, s, &ix);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(d_text);
+  return rc == kOk ? ix : nullptr;
+}
+
+}  // extern "C"

@@ -1,19 +1,734 @@
-// placeholder until the SA kernels land
+// Suffix-array construction for 2-bit packed texts on gfx950.
+//
+// Replaces histsort (histsortcomp.c:161-180) and csuff_arr (csacak.c:521-528).
+// The reference sorts one base per level by count + scatter (histhelper,
+// histsortcomp.c:35-90).  Here a level consumes four bases (256 buckets):
+//   1. k_part_hist     LDS-privatised k-mer histogram per 4096-suffix tile,
+//                      merged into per-segment counters
+//   2. k_part_classify per-segment prefix sum -> child bucket cursors; children
+//                      above kLeafMax rows go to the next level, runs of small
+//                      neighbours are merged into leaves
+//   3. k_part_scatter  tile-local bucket order in LDS, then runs of each
+//                      bucket are written to the segment's cursors
+// Leaves (<= kLeafMax suffixes sharing `depth` bases) are sorted in LDS by the
+// next 16 bases (k_leaf_sort).  Suffixes that still tie, and buckets that never
+// shrink (repeats), go to prefix doubling (sa_doubling below), which is what
+// keeps tandem repeats from costing O(n * LCP) as they do in the reference.
+//
+// Order being computed: suffixes compare as their bases followed by an
+// end-of-text symbol smaller than A (histsortcomp.c:54-64 puts the suffix that
+// ends first).  Padding the text with A (zeros) and breaking exact ties by
+// "larger start first" gives the same order, so keys never need a fifth symbol.
 #include "common.hpp"
+#include "radix_sort.hpp"
+#include "scan.hpp"
+
+namespace bwtgpu {
+
+constexpr int kPartThreads = 256;
+constexpr int kPartItems = 16;
+constexpr int kPartTile = kPartThreads * kPartItems;  // 4096 suffixes per tile
+constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
+constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
+constexpr uint32_t kMaxDepth = 24;                    // bucket levels stop here; doubling takes over
+constexpr uint32_t kLeafKeyBases = 16;                // bases in a leaf sort key
+constexpr uint32_t kTextPadWords = 8;
+
+enum : uint32_t { kSrcA = 0, kSrcB = 1, kSrcImplicit = 2 };
+
+struct Seg {
+  uint32_t start, size;  // rows [start, start+size) of SA+1 (row 0 of the SA is the $ suffix)
+};
+struct Leaf {
+  uint32_t start, size, depth, src;
+};
+
+struct Counters {
+  uint32_t nnext;       // segments emitted for the next level
+  uint32_t nleaves;
+  uint32_t unresolved;  // rows left in tie groups
+  uint32_t min_depth;   // smallest number of bases any tie group is sorted by
+  uint32_t overflow;    // a list ran out of room (reported as an error)
+  uint32_t total_tiles;
+  uint32_t active;      // doubling: rows still in groups
+  uint32_t pad;
+};
+
+// ---- text -------------------------------------------------------------
+
+// Big-endian 16-base words of the text: base i at bits 31-2*(i&15) of word
+// i>>4, zeros from base n on, kTextPadWords words of zeros after the end.
+__global__ void k_prepare_text(const uint8_t *__restrict__ text, uint32_t n, uint64_t nwords,
+                               uint32_t *__restrict__ tb) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  const uint64_t nbytes = (uint64_t)n / 4 + 1;
+  uint32_t v = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint64_t b = 4 * w + k;
+    v = (v << 8) | (b < nbytes ? text[b] : 0u);
+  }
+  const uint64_t first = 16 * w;
+  const uint32_t valid = first >= n ? 0u : (n - first >= 16 ? 16u : (uint32_t)(n - first));
+  const uint32_t mask = valid == 16 ? ~0u : (valid == 0 ? 0u : ~((1u << (32 - 2 * valid)) - 1u));
+  tb[w] = v & mask;
+}
+
+// 16 bases starting at position p, first base in the top bits
+__device__ __forceinline__ uint32_t key32(const uint32_t *__restrict__ tb, uint64_t p) {
+  const uint64_t w = p >> 4;
+  const uint32_t sh = 2u * (uint32_t)(p & 15u);
+  const uint64_t both = ((uint64_t)tb[w] << 32) | tb[w + 1];
+  return (uint32_t)((both << sh) >> 32);
+}
+
+// ---- one bucket level ----------------------------------------------------
+
+// which segment a tile belongs to: last s with tile_first[s] <= tile
+__device__ __forceinline__ uint32_t find_segment(const uint32_t *tile_first, uint32_t nsegs,
+                                                 uint32_t tile) {
+  uint32_t lo = 0, hi = nsegs;  // invariant: tile_first[lo] <= tile < tile_first[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (tile_first[mid] <= tile) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+struct TileInfo {
+  uint32_t seg, row0, count;
+};
+
+__device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *tile_first,
+                                            uint32_t nsegs, const Counters *ctr, TileInfo *sh) {
+  if (threadIdx.x == 0) {
+    const uint32_t tile = blockIdx.x;
+    if (tile >= ctr->total_tiles) {
+      sh->count = 0;
+    } else {
+      const uint32_t s = find_segment(tile_first, nsegs, tile);
+      const Seg sg = segs[s];
+      const uint32_t off = (tile - tile_first[s]) * (uint32_t)kPartTile;
+      sh->seg = s;
+      sh->row0 = sg.start + off;
+      const uint32_t left = sg.size - off;
+      sh->count = left < (uint32_t)kPartTile ? left : (uint32_t)kPartTile;
+    }
+  }
+  __syncthreads();
+  return sh->count != 0;
+}
+
+// LDS-privatised histogram of the next four bases of every suffix in a tile.
+template <bool IMPLICIT>
+__global__ void __launch_bounds__(kPartThreads)
+k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
+            const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+            uint32_t depth, const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
+  __shared__ uint32_t hist[256];
+  __shared__ TileInfo ti;
+  hist[threadIdx.x] = 0;
+  if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
+  const uint32_t row0 = ti.row0, count = ti.count;
+#pragma unroll 4
+  for (int i = 0; i < kPartItems; ++i) {
+    const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
+    if (j < count) {
+      const uint32_t id = IMPLICIT ? row0 + j : src[row0 + j];
+      atomicAdd(&hist[key32(tb, (uint64_t)id + depth) >> 24], 1u);
+    }
+  }
+  __syncthreads();
+  const uint32_t c = hist[threadIdx.x];
+  if (c) atomicAdd(&seg_counts[(uint64_t)ti.seg * 256 + threadIdx.x], c);
+}
+
+// One workgroup per segment: counts -> absolute cursors of the 256 children;
+// children above kLeafMax become next-level segments, runs of smaller
+// neighbours are merged into leaves (a merged leaf is sorted from the parent's
+// depth, so the bases that separate the merged children are part of its key).
+__global__ void __launch_bounds__(256)
+k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
+                uint32_t dst_id, Seg *__restrict__ next_segs, uint32_t next_cap,
+                Leaf *__restrict__ leaves, uint32_t leaf_cap, Counters *__restrict__ ctr) {
+  __shared__ uint32_t sizes[256], starts[256], wsum[4];
+  const uint32_t s = blockIdx.x, t = threadIdx.x;
+  const Seg sg = segs[s];
+  const uint32_t c = seg_counts[(uint64_t)s * 256 + t];
+  uint32_t v = c;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+  const uint32_t start = sg.start + pre + v - c;
+  seg_counts[(uint64_t)s * 256 + t] = start;  // becomes the scatter cursor
+  sizes[t] = c;
+  starts[t] = start;
+  __syncthreads();
+  if (t != 0) return;
+  uint32_t run_start = 0, run_size = 0;
+  auto flush = [&]() {
+    if (!run_size) return;
+    const uint32_t k = atomicAdd(&ctr->nleaves, 1u);
+    if (k < leaf_cap) leaves[k] = Leaf{run_start, run_size, depth, dst_id};
+    else ctr->overflow = 1;
+    run_size = 0;
+  };
+  for (int d = 0; d < 256; ++d) {
+    const uint32_t sz = sizes[d];
+    if (!sz) continue;
+    if (sz > kLeafMax) {
+      flush();
+      const uint32_t k = atomicAdd(&ctr->nnext, 1u);
+      if (k < next_cap) next_segs[k] = Seg{starts[d], sz};
+      else ctr->overflow = 1;
+    } else {
+      if (run_size + sz > kLeafMax) flush();
+      if (!run_size) run_start = starts[d];
+      run_size += sz;
+    }
+  }
+  flush();
+}
+
+__global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
+                                  uint32_t *__restrict__ tiles) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsegs) tiles[s] = (segs[s].size + kPartTile - 1) / kPartTile;
+}
+
+// Tile-local bucket order in LDS, then each bucket's run goes to the
+// segment's cursor for that bucket (one atomic per tile and bucket).  Order
+// inside a bucket is irrelevant at this stage.
+template <bool IMPLICIT>
+__global__ void __launch_bounds__(kPartThreads)
+k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
+               uint32_t *__restrict__ dst, const Seg *__restrict__ segs,
+               const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
+               const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors) {
+  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4];
+  __shared__ uint32_t ids[kPartTile];
+  __shared__ uint8_t digs[kPartTile];
+  __shared__ TileInfo ti;
+  const uint32_t t = threadIdx.x;
+  hist[t] = 0;
+  fill[t] = 0;
+  if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
+  const uint32_t row0 = ti.row0, count = ti.count;
+  uint32_t id[kPartItems], dg[kPartItems];
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const uint32_t j = (uint32_t)i * kPartThreads + t;
+    if (j < count) {
+      id[i] = IMPLICIT ? row0 + j : src[row0 + j];
+      dg[i] = key32(tb, (uint64_t)id[i] + depth) >> 24;
+      atomicAdd(&hist[dg[i]], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the 256 bucket counts; claim global room per bucket
+  const uint32_t c = hist[t];
+  uint32_t v = c;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+  lstart[t] = pre + v - c;
+  gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPartItems; ++i) {
+    const uint32_t j = (uint32_t)i * kPartThreads + t;
+    if (j < count) {
+      const uint32_t p = lstart[dg[i]] + atomicAdd(&fill[dg[i]], 1u);
+      ids[p] = id[i];
+      digs[p] = (uint8_t)dg[i];
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = t; j < count; j += kPartThreads) {
+    const uint32_t d = digs[j];
+    dst[gbase[d] + (j - lstart[d])] = ids[j];
+  }
+}
+
+// ---- leaves ---------------------------------------------------------------
+
+// One workgroup sorts one leaf in LDS by (next 16 bases ascending, start
+// descending), writes the rows of the suffix array, and records for every row
+// the first row of its tie group (its own row when resolved).
+__global__ void __launch_bounds__(256)
+k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+            const uint32_t *__restrict__ bufB, const Leaf *__restrict__ leaves, uint32_t n,
+            uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
+            Counters *__restrict__ ctr) {
+  __shared__ uint64_t keys[kLeafMax];
+  __shared__ uint32_t wred[4];
+  const Leaf lf = leaves[blockIdx.x];
+  const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
+  const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
+  if (size == 1) {
+    if (t == 0) {
+      const uint32_t id = src ? src[start] : start;
+      sa_rows[start] = id;
+      ghead[1 + start] = 1 + start;
+    }
+    return;
+  }
+  uint32_t P = 2;
+  while (P < size) P <<= 1;
+  for (uint32_t j = t; j < P; j += 256) {
+    uint64_t v = ~0ull;
+    if (j < size) {
+      const uint32_t id = src ? src[start + j] : start + j;
+      v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
+    }
+    keys[j] = v;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t q = t; q < (P >> 1); q += 256) {
+        const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+        const uint32_t x = i | j;
+        const uint64_t a = keys[i], b = keys[x];
+        const bool asc = (i & k) == 0;
+        if ((a > b) == asc) {
+          keys[i] = b;
+          keys[x] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // tie flags and group heads, blocked: thread t owns rows [t*per, t*per+per)
+  const uint32_t per = (P + 255) / 256;  // 1..16
+  const uint32_t j0 = t * per;
+  uint32_t hv[16];
+  uint32_t local_max = 0, tied_rows = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    hv[k] = 0;
+    const uint32_t j = j0 + k;
+    if (k < per && j < size) {
+      bool tie = false, tie_next = false;
+      const uint64_t cur = keys[j];
+      if (j > 0) {
+        const uint64_t prv = keys[j - 1];
+        const uint32_t pid = ~(uint32_t)prv;
+        // the previous suffix is final here if its key window ran past the
+        // end of the text: a shorter suffix precedes every longer one it ties
+        tie = (uint32_t)(prv >> 32) == (uint32_t)(cur >> 32) &&
+              (uint64_t)pid + depth + kLeafKeyBases < n;
+      }
+      if (j + 1 < size) {
+        const uint64_t nxt = keys[j + 1];
+        const uint32_t cid = ~(uint32_t)cur;
+        tie_next = (uint32_t)(nxt >> 32) == (uint32_t)(cur >> 32) &&
+                   (uint64_t)cid + depth + kLeafKeyBases < n;
+      }
+      hv[k] = tie ? 0u : 1u + start + j;
+      tied_rows += (tie || tie_next) ? 1u : 0u;
+      local_max = hv[k] > local_max ? hv[k] : local_max;
+    }
+  }
+  // inclusive max-scan of local_max over threads
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  uint32_t v = local_max;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v = u > v ? u : v;
+  }
+  uint32_t tr = tied_rows;
+  for (int off = 32; off; off >>= 1) tr += __shfl_down(tr, off, 64);
+  __shared__ uint32_t wmax[4];
+  if (lane == 63) wmax[wave] = v;
+  if (lane == 0) wred[wave] = tr;
+  __syncthreads();
+  uint32_t before = 0;  // max over all earlier threads
+  for (uint32_t w = 0; w < wave; ++w) before = wmax[w] > before ? wmax[w] : before;
+  const uint32_t up = __shfl_up(v, 1, 64);
+  if (lane) before = up > before ? up : before;
+  if (t == 0) {
+    const uint32_t total = wred[0] + wred[1] + wred[2] + wred[3];
+    if (total) {
+      atomicAdd(&ctr->unresolved, total);
+      atomicMin(&ctr->min_depth, depth + kLeafKeyBases);
+    }
+  }
+  // every thread has read its neighbours' keys; now reuse the LDS slots
+  uint32_t run = before;
+  uint64_t outv[16];
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint32_t j = j0 + k;
+    if (k < per && j < size) {
+      run = hv[k] > run ? hv[k] : run;
+      outv[k] = ((uint64_t)run << 32) | (uint32_t)~(uint32_t)keys[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < 16; ++k) {
+    const uint32_t j = j0 + k;
+    if (k < per && j < size) keys[j] = outv[k];
+  }
+  __syncthreads();
+  for (uint32_t j = t; j < size; j += 256) {
+    const uint64_t o = keys[j];
+    sa_rows[start + j] = (uint32_t)o;
+    ghead[1 + start + j] = (uint32_t)(o >> 32);
+  }
+}
+
+// Segments still above kLeafMax when the bucket levels stop: one tie group
+// each.  Suffixes shorter than `depth` got here through the zero padding; they
+// precede the rest of their segment, shortest first, and are final.  There are
+// fewer than `depth` of them in the whole text.
+__global__ void __launch_bounds__(256)
+k_unresolved_segs(const Seg *__restrict__ segs, const uint32_t *__restrict__ src,
+                  uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint32_t depth,
+                  uint32_t n, Counters *__restrict__ ctr) {
+  __shared__ uint32_t short_rows[kMaxDepth + 8];
+  __shared__ uint32_t nshort;
+  const Seg sg = segs[blockIdx.x];
+  if (threadIdx.x == 0) nshort = 0;
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < sg.size; j += 256) {
+    const uint32_t row = sg.start + j;
+    const uint32_t id = src[row];
+    sa_rows[row] = id;
+    if ((uint64_t)id + depth > n) {
+      const uint32_t k = atomicAdd(&nshort, 1u);
+      if (k < kMaxDepth + 8) short_rows[k] = row;
+    }
+  }
+  __syncthreads();
+  const uint32_t E = nshort;
+  if (threadIdx.x == 0 && E) {
+    // move the short suffixes to the first E rows (the order of the others is
+    // free), then order them by decreasing start
+    uint32_t lo = sg.start;
+    for (uint32_t k = 0; k < E; ++k) {
+      const uint32_t r = short_rows[k];
+      if (r < sg.start + E) continue;  // already in the front part
+      while ((uint64_t)sa_rows[lo] + depth > n) ++lo;  // first front row holding a long suffix
+      const uint32_t tmp = sa_rows[lo];
+      sa_rows[lo] = sa_rows[r];
+      sa_rows[r] = tmp;
+      ++lo;
+    }
+    for (uint32_t a = 1; a < E; ++a) {
+      const uint32_t v = sa_rows[sg.start + a];
+      uint32_t b = a;
+      while (b > 0 && sa_rows[sg.start + b - 1] < v) {
+        sa_rows[sg.start + b] = sa_rows[sg.start + b - 1];
+        --b;
+      }
+      sa_rows[sg.start + b] = v;
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < sg.size; j += 256)
+    ghead[1 + sg.start + j] = j < E ? 1 + sg.start + j : 1 + sg.start + E;
+  if (threadIdx.x == 0 && sg.size - E >= 2) {
+    atomicAdd(&ctr->unresolved, sg.size - E);
+    atomicMin(&ctr->min_depth, depth);
+  }
+}
+
+// ---- prefix doubling over the remaining tie groups -------------------------------
+
+__global__ void k_isa_init(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ ghead,
+                           uint32_t *__restrict__ isa, uint64_t rows) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < rows) isa[sa[j]] = ghead[j];
+}
+
+__global__ void k_mark_active(const uint32_t *__restrict__ ghead, uint32_t *__restrict__ flags,
+                              uint64_t rows) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows) return;
+  const bool tied_prev = ghead[j] != (uint32_t)j;
+  const bool tied_next = j + 1 < rows && ghead[j + 1] == (uint32_t)j;
+  flags[j] = (tied_prev || tied_next) ? 1u : 0u;
+}
+
+__global__ void k_compact_keys(const uint32_t *__restrict__ flags, const uint32_t *__restrict__ offs,
+                               const uint32_t *__restrict__ sa, const uint32_t *__restrict__ ghead,
+                               const uint32_t *__restrict__ isa, uint32_t n, uint64_t h, int kb,
+                               uint64_t rows, uint32_t *__restrict__ rowof,
+                               uint64_t *__restrict__ K, uint32_t *__restrict__ V) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows || !flags[j]) return;
+  const uint32_t a = offs[j];
+  const uint32_t id = sa[j];
+  const uint64_t nxt = (uint64_t)id + h;
+  // a suffix in a tie group shares at least h bases with another, so id+h <= n;
+  // row 0 (rank 0) is the end-of-text suffix and orders a suffix that ends
+  // exactly there before the others
+  const uint32_t key2 = nxt <= n ? isa[nxt] : 0u;
+  rowof[a] = (uint32_t)j;
+  K[a] = ((uint64_t)ghead[j] << kb) | key2;
+  V[a] = id;
+}
+
+__global__ void k_group_heads(const uint64_t *__restrict__ K, const uint32_t *__restrict__ rowof,
+                              uint32_t A, uint32_t *__restrict__ hv) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  hv[a] = (a == 0 || K[a] != K[a - 1]) ? rowof[a] : 0u;
+}
+
+__global__ void k_doubling_apply(const uint32_t *__restrict__ V, const uint32_t *__restrict__ rowof,
+                                 const uint32_t *__restrict__ newhead, uint32_t A,
+                                 uint32_t *__restrict__ sa, uint32_t *__restrict__ ghead,
+                                 uint32_t *__restrict__ isa) {
+  const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const uint32_t row = rowof[a], id = V[a], head = newhead[a];
+  sa[row] = id;
+  ghead[row] = head;
+  isa[id] = head;
+}
+
+struct SaStats {
+  uint64_t v[8];
+};
+static thread_local SaStats g_stats;
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// SA rows partly ordered, ghead[row] = first row of the row's tie group (full
+// row numbering, row 0 = the $ suffix), every tie group ordered by at least h0
+// bases.  Finishes the order by prefix doubling restricted to the tie groups.
+static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0, uint32_t *flags,
+                       Counters *d_ctr, hipStream_t s) {
+  const uint64_t rows = (uint64_t)n + 1;
+  int kb = 1;
+  while (kb < 32 && (n >> kb)) ++kb;  // values <= n fit in kb bits
+  DevBuf isa, offs, scanws;
+  hipError_t e = isa.alloc(rows * 4);
+  if (e == hipSuccess) e = offs.alloc(rows * 4);
+  if (e == hipSuccess) e = scanws.alloc(scan_workspace_bytes(rows));
+  if (e != hipSuccess) return set_error(kErrHip, "prefix doubling buffers: %s", hipGetErrorString(e));
+  const unsigned gr = (unsigned)div_up(rows, 256);
+  BWT_LAUNCH("dbl_isa_init", k_isa_init, dim3(gr), dim3(256), 0, s, d_sa, ghead, isa.as<uint32_t>(), rows);
+  DevBuf K, Kalt, V, Valt, rowof, hv, sortws;
+  uint64_t cap = 0;
+  uint64_t h = h0 ? h0 : 1;
+  uint32_t prevA = 0xFFFFFFFFu;
+  for (int round = 0; round < 64; ++round) {
+    BWT_LAUNCH("dbl_mark_active", k_mark_active, dim3(gr), dim3(256), 0, s, ghead, flags, rows);
+    BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, flags, offs.as<uint32_t>(), rows, &d_ctr->active,
+                            scanws.p, scan_workspace_bytes(rows), s));
+    uint32_t A = 0;
+    BWT_HIP(hipMemcpyAsync(&A, &d_ctr->active, 4, hipMemcpyDeviceToHost, s));
+    BWT_HIP(hipStreamSynchronize(s));
+    if (A == 0) {
+      g_stats.v[3] = round;
+      return kOk;
+    }
+    if (A > prevA) return set_error(kErrInternal, "prefix doubling: active rows grew %u -> %u", prevA, A);
+    prevA = A;
+    if (!cap) {
+      cap = A;
+      e = K.alloc(cap * 8);
+      if (e == hipSuccess) e = Kalt.alloc(cap * 8);
+      if (e == hipSuccess) e = V.alloc(cap * 4);
+      if (e == hipSuccess) e = Valt.alloc(cap * 4);
+      if (e == hipSuccess) e = rowof.alloc(cap * 4);
+      if (e == hipSuccess) e = hv.alloc(cap * 4);
+      if (e == hipSuccess) e = sortws.alloc(radix_sort_workspace_bytes(cap));
+      if (e != hipSuccess) return set_error(kErrHip, "prefix doubling sort buffers: %s", hipGetErrorString(e));
+    }
+    BWT_LAUNCH("dbl_compact_keys", k_compact_keys, dim3(gr), dim3(256), 0, s, flags, offs.as<uint32_t>(),
+               d_sa, ghead, isa.as<uint32_t>(), n, h, kb, rows, rowof.as<uint32_t>(), K.as<uint64_t>(),
+               V.as<uint32_t>());
+    BWT_TRY(radix_sort_pairs(K.as<uint64_t>(), V.as<uint32_t>(), Kalt.as<uint64_t>(), Valt.as<uint32_t>(),
+                             A, 2 * kb, sortws.p, radix_sort_workspace_bytes(cap), s));
+    const unsigned ga = (unsigned)div_up(A, 256);
+    BWT_LAUNCH("dbl_group_heads", k_group_heads, dim3(ga), dim3(256), 0, s, K.as<uint64_t>(),
+               rowof.as<uint32_t>(), A, hv.as<uint32_t>());
+    BWT_TRY(device_scan_u32(ScanOp::kMaxInclusive, hv.as<uint32_t>(), hv.as<uint32_t>(), A, nullptr,
+                            scanws.p, scan_workspace_bytes(rows), s));
+    BWT_LAUNCH("dbl_apply", k_doubling_apply, dim3(ga), dim3(256), 0, s, V.as<uint32_t>(),
+               rowof.as<uint32_t>(), hv.as<uint32_t>(), A, d_sa, ghead, isa.as<uint32_t>());
+    BWT_CHECK_LAUNCH();
+    h *= 2;
+  }
+  return set_error(kErrInternal, "prefix doubling did not converge");
+}
+
+// ---- driver -------------------------------------------------------------------
+
+struct Layout {
+  size_t tb, bufB, ghead, segs0, segs1, counts, tile_first, leaves, ctr, scanws, end;
+  uint64_t nwords;
+  uint32_t seg_cap, leaf_cap;
+};
+
+static Layout layout_for(uint32_t n) {
+  Layout L;
+  L.nwords = (uint64_t)n / 16 + 1 + kTextPadWords;
+  L.seg_cap = n / kLeafMax + 512;       // a next-level segment holds > kLeafMax rows
+  L.leaf_cap = n / 128 + 8192;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t at = off;
+    off += align_up(bytes, 256);
+    return at;
+  };
+  L.tb = take(L.nwords * 4);
+  L.bufB = take(((size_t)n + 1) * 4);
+  L.ghead = take(((size_t)n + 1) * 4);
+  L.segs0 = take((size_t)L.seg_cap * sizeof(Seg));
+  L.segs1 = take((size_t)L.seg_cap * sizeof(Seg));
+  L.counts = take((size_t)L.seg_cap * 256 * 4);
+  L.tile_first = take(((size_t)L.seg_cap + 1) * 4);
+  L.leaves = take((size_t)L.leaf_cap * sizeof(Leaf));
+  L.ctr = take(sizeof(Counters));
+  L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
+  L.end = off;
+  return L;
+}
+
+int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,
+                  hipStream_t s) {
+  if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
+  if (n == 0 || n > 0xFFFFFFF0u) return set_error(kErrArg, "text length %u out of range", n);
+  if ((uintptr_t)d_ws & 255u) return set_error(kErrArg, "workspace must be 256-byte aligned");
+  const Layout L = layout_for(n);
+  if (ws_bytes < L.end) return set_error(kErrWorkspace, "SA workspace %zu < %zu bytes", ws_bytes, L.end);
+  uint8_t *ws = reinterpret_cast<uint8_t *>(d_ws);
+  uint32_t *tb = reinterpret_cast<uint32_t *>(ws + L.tb);
+  uint32_t *bufA = d_sa + 1;
+  uint32_t *bufB = reinterpret_cast<uint32_t *>(ws + L.bufB);
+  uint32_t *ghead = reinterpret_cast<uint32_t *>(ws + L.ghead);
+  Seg *segs[2] = {reinterpret_cast<Seg *>(ws + L.segs0), reinterpret_cast<Seg *>(ws + L.segs1)};
+  uint32_t *counts = reinterpret_cast<uint32_t *>(ws + L.counts);
+  uint32_t *tile_first = reinterpret_cast<uint32_t *>(ws + L.tile_first);
+  Leaf *leaves = reinterpret_cast<Leaf *>(ws + L.leaves);
+  Counters *ctr = reinterpret_cast<Counters *>(ws + L.ctr);
+  void *scanws = ws + L.scanws;
+  const size_t scanws_bytes = scan_workspace_bytes(L.seg_cap + 1);
+  g_stats = SaStats{};
+
+  BWT_LAUNCH("sa_prepare_text", k_prepare_text, dim3((unsigned)div_up(L.nwords, 256)), dim3(256), 0, s,
+             d_text, n, L.nwords, tb);
+  Counters h_ctr = {};
+  h_ctr.min_depth = 0xFFFFFFFFu;
+  BWT_HIP(hipMemcpyAsync(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
+  // row 0 of the suffix array is the end-of-text suffix (histsortcomp.c:165)
+  const uint32_t row0[1] = {n};
+  BWT_HIP(hipMemcpyAsync(d_sa, row0, 4, hipMemcpyHostToDevice, s));
+  BWT_HIP(hipMemsetAsync(ghead, 0, 4, s));
+
+  uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
+  int cur = 0;
+  uint32_t nleaves_host = 0;
+  if (n <= kLeafMax) {
+    const Leaf whole = {0, n, 0, kSrcImplicit};
+    BWT_HIP(hipMemcpyAsync(leaves, &whole, sizeof whole, hipMemcpyHostToDevice, s));
+    nleaves_host = 1;
+  } else {
+    const Seg whole = {0, n};
+    BWT_HIP(hipMemcpyAsync(segs[0], &whole, sizeof whole, hipMemcpyHostToDevice, s));
+    nsegs = 1;
+  }
+  int levels = 0;
+  while (nsegs > 0 && depth < kMaxDepth) {
+    const uint32_t dst_id = src_id == kSrcA ? kSrcB : kSrcA;
+    const uint32_t *src = src_id == kSrcA ? bufA : src_id == kSrcB ? bufB : nullptr;
+    uint32_t *dst = dst_id == kSrcA ? bufA : bufB;
+    // tiles of this level's segments
+    BWT_LAUNCH("sa_seg_tiles", k_seg_tile_counts, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s,
+               segs[cur], nsegs, tile_first);
+    BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tile_first, tile_first, nsegs, &ctr->total_tiles,
+                            scanws, scanws_bytes, s));
+    BWT_HIP(hipMemsetAsync(counts, 0, (size_t)nsegs * 256 * 4, s));
+    BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
+    const unsigned tile_bound = (unsigned)((uint64_t)n / kPartTile + nsegs + 1);
+    if (src_id == kSrcImplicit) {
+      BWT_LAUNCH("sa_part_hist", k_part_hist<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src,
+                 segs[cur], tile_first, nsegs, depth, ctr, counts);
+    } else {
+      BWT_LAUNCH("sa_part_hist", k_part_hist<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src,
+                 segs[cur], tile_first, nsegs, depth, ctr, counts);
+    }
+    BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
+               dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, ctr);
+    if (src_id == kSrcImplicit) {
+      BWT_LAUNCH("sa_part_scatter", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
+                 src, dst, segs[cur], tile_first, nsegs, depth, ctr, counts);
+    } else {
+      BWT_LAUNCH("sa_part_scatter", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
+                 src, dst, segs[cur], tile_first, nsegs, depth, ctr, counts);
+    }
+    BWT_CHECK_LAUNCH();
+    BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+    BWT_HIP(hipStreamSynchronize(s));
+    if (h_ctr.overflow) return set_error(kErrInternal, "SA build: bucket list overflow at depth %u", depth);
+    nsegs = h_ctr.nnext;
+    nleaves_host = h_ctr.nleaves;
+    cur ^= 1;
+    src_id = dst_id;
+    depth += kDigitBases;
+    ++levels;
+  }
+  g_stats.v[0] = levels;
+  g_stats.v[1] = nleaves_host;
+  g_stats.v[4] = depth;
+  if (nleaves_host)
+    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(256), 0, s, tb, bufA, bufB, leaves, n,
+               bufA, ghead, ctr);
+  if (nsegs) {
+    const uint32_t *src = src_id == kSrcA ? bufA : bufB;
+    BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
+               ghead, depth, n, ctr);
+  }
+  BWT_CHECK_LAUNCH();
+  BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+  BWT_HIP(hipStreamSynchronize(s));
+  g_stats.v[2] = h_ctr.unresolved;
+  if (h_ctr.unresolved) {
+    // bufB is free from here on: reuse it for the active-row flags
+    BWT_TRY(sa_doubling(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
+  }
+  return kOk;
+}
+
+}  // namespace bwtgpu
+
 using namespace bwtgpu;
+
 extern "C" {
-size_t bwtgpu_sa_workspace_bytes(uint32_t n) { return 256 + (size_t)n; }
-int bwtgpu_sa_build(const uint8_t *, uint32_t, uint32_t *, void *, size_t, void *) {
-  return set_error(kErrInternal, "sa_build not implemented");
+
+size_t bwtgpu_sa_workspace_bytes(uint32_t n) { return layout_for(n ? n : 1).end; }
+
+int bwtgpu_sa_build(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,
+                    void *stream) {
+  return sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, (hipStream_t)stream);
 }
-int bwtgpu_sa_last_stats(uint64_t s[8]) { for (int i = 0; i < 8; ++i) s[i] = 0; return 0; }
-int bwtgpu_bwt_from_sa(const uint8_t *, const uint32_t *, uint32_t, uint8_t *, uint32_t *, void *) {
-  return set_error(kErrInternal, "bwt_from_sa not implemented");
+
+int bwtgpu_sa_last_stats(uint64_t stats[8]) {
+  for (int i = 0; i < 8; ++i) stats[i] = g_stats.v[i];
+  return kOk;
 }
-bwtgpu_index *bwtgpu_index_build(const uint8_t *, uint32_t, void *) {
-  set_error(kErrInternal, "index_build not implemented"); return nullptr;
-}
-bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *, uint32_t, void *) {
-  set_error(kErrInternal, "index_build not implemented"); return nullptr;
-}
-}
+
+}  // extern "C"

@@ -114,6 +114,15 @@ int bwtgpu_gen_reads(const uint8_t *d_text, uint64_t n, uint8_t *d_reads,
                      uint64_t R, uint32_t m, uint64_t seed, uint32_t *d_offsets,
                      void *stream);
 
+/* ---- diagnostics: drive internal device primitives from the tests ---- */
+/* No counterpart in the reference.  op 0: exclusive add scan, 1: inclusive
+ * max scan, over uint32; allocate their own scratch and synchronise. */
+int bwtgpu_diag_scan(int op, const uint32_t *d_in, uint32_t *d_out, uint64_t count,
+                     uint32_t *d_total, void *stream);
+/* stable sort of (uint64 key, uint32 value) pairs by key bits [0, key_bits) */
+int bwtgpu_diag_radix_sort(uint64_t *d_keys, uint32_t *d_vals, uint64_t count,
+                           int key_bits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
