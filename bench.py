@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the two hot paths on MI355X.
+
+Workload at N=1 (BASELINE.json configs[1]): a 46 Mbp synthetic genome,
+FM-index build on device (SA + BWT + sampled SA + rank blocks), and 10 M
+50-bp exact-match reads searched per step.  A "step" is one backward-search
+pass over the rank's whole read batch with the reads already in HBM.  At N>1
+the index is replicated per GPU (each rank builds it) and every rank searches
+its own batch of the same size (weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0.  `value` = reads/s over all ranks; the SA/BWT
+build rate, the locate rate, the roofline figures of the dominant kernel and
+the CPU baseline ride in the same line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from bwt_amd import gpu as G  # noqa: E402
+from bwt_amd import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def search_bytes_per_read(m, locate_steps=None):
+    """Algorithmic HBM bytes per read: m/4 packed pattern + one 32-byte index
+    block per rank query (2 per backward-search step) + 8 bytes of (sp, ep);
+    with locate, one block per LF step + 4 bytes of position."""
+    b = m / 4 + 32.0 * 2 * (m - 1) + 8
+    if locate_steps is not None:
+        b += 32.0 * locate_steps + 4
+    return b
+
+
+def cpu_baseline(args, d_text, n, d_reads, R, m, gpu_sp, gpu_ep):
+    """The reference (oracle/_ref, when built) or the oracle port, timed on the
+    host cores on a bounded sample of the same workload."""
+    from oracle import load_oracle, load_reference
+
+    ref = None if args.cpu_port else load_reference()
+    orc = load_oracle()
+    text = d_text[: n // 4 + 1].cpu().numpy()
+    sample = min(R, args.cpu_reads)
+    reads = d_reads[: sample * m].cpu().numpy()
+    out = {"cores": 4, "kind": "reference" if ref else "port"}
+    t0 = time.perf_counter()
+    fmi = ref.make_fmi(text, n) if ref else orc.make_fmi(text, n)
+    t_build = time.perf_counter() - t0
+    impl = ref if ref else orc
+    t0 = time.perf_counter()
+    sp, ep = impl.search_batch(fmi, reads, m, m, sample, threads=4)
+    t_search = time.perf_counter() - t0
+    ok = bool((sp == gpu_sp[:sample]).all() and (ep == gpu_ep[:sample]).all())
+    out.update({
+        "value": sample / t_search,
+        "unit": "reads/s",
+        "sample": f"{sample} of the {R} reads ({m} bp), 4 threads as fmitest.c:70; "
+                  f"index built by make_fmi on the same {n} bp genome (4 threads, histsortcomp.c:117)",
+        "build_mbp_s": n / t_build / 1e6,
+        "build_s": t_build,
+        "search_s": t_search,
+        "host_cpus": os.cpu_count(),
+        "gpu_matches_cpu": ok,
+    })
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--genome-bp", type=int, default=46_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=50)
+    ap.add_argument("--build-reps", type=int, default=3)
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    G.init(local_rank)
+
+    n, R, m = args.genome_bp, args.reads, args.read_len
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- inputs, generated in HBM (same genome on every rank, own reads) ----
+    d_text = G.gen_genome(n, synth.GENOME_SEED)
+    torch.cuda.synchronize()
+
+    # ---- HP1: FM-index build from the HBM-resident text ----
+    G.timing_enable(True)
+    G.timing_reset()
+    ix = None
+    build_ms = []
+    for rep in range(args.build_reps + 1):
+        if ix is not None:
+            ix.close()
+        if rep == 1:
+            G.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix = G.build_index_dev(d_text, n)
+        torch.cuda.synchronize()
+        if rep >= 1 or args.build_reps == 0:
+            build_ms.append((time.perf_counter() - t0) * 1e3)
+    build_kernels = G.timing_report()
+    sa_stats = G.sa_last_stats()
+    build_s = float(np.median(build_ms)) / 1e3
+
+    d_reads, _ = G.gen_reads(d_text, n, R, m, synth.READS_SEED + rank, want_offsets=False)
+    sp = torch.empty(R, dtype=torch.int32, device="cuda")
+    ep = torch.empty(R, dtype=torch.int32, device="cuda")
+    lr = torch.empty(R, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+
+    # ---- HP2: backward search, timed region ----
+    G.timing_enable(False)
+    for _ in range(args.warmup):
+        ix.search(d_reads, m, R, want_locrow=True, out=(sp, ep, lr))
+    G.timing_enable(True)
+    G.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ix.search(d_reads, m, R, want_locrow=True, out=(sp, ep, lr))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    search_kernels = G.timing_report()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- locate (unc_sa) of every read's first row: reported beside, not in value ----
+    G.timing_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pos, lf_steps = ix.locate_rows(lr, count_steps=True)
+    torch.cuda.synchronize()
+    locate_s = time.perf_counter() - t0
+    locate_kernels = G.timing_report()
+    located = int((pos != -1).sum().item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    n_launch, ms_total = search_kernels.get("fm_search", (0, 0.0))
+    k_ms = ms_total / max(n_launch, 1)
+    bpr = search_bytes_per_read(m)
+    achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+    loc_launch, loc_ms = locate_kernels.get("fm_locate", (0, 0.0))
+    loc_bytes = 32.0 * lf_steps + 8.0 * located
+    sa_ms = sum(v[1] / max(args.build_reps, 1) for k, v in build_kernels.items()
+                if k.startswith(("sa_", "dbl_", "rs_", "scan_")))
+    result = {
+        "metric": "SA build Mbp/s; FM backward-search reads/s (1/2/4/8 GPU); % HBM peak",
+        "value": world * R * args.steps / elapsed,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n / 1e6:g} Mbp splitmix64 genome, FM-index built on device, "
+                        f"{R} x {m} bp exact-match reads per GPU per step (1% random), index replicated",
+            "genome_bp": n, "reads_per_gpu": R, "read_len": m,
+        },
+        "roofline": {
+            "kernel": "fm_search",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_read": bpr,
+            "kernel_ms": k_ms,
+        },
+        "sa_build": {
+            "value": n / build_s / 1e6,
+            "unit": "Mbp/s",
+            "wall_ms": build_s * 1e3,
+            "what": "make_fmi on device: text in HBM -> SA, BWT, sampled SA, rank blocks, C[] (SA stays in HBM)",
+            "sa_kernels_ms": sa_ms,
+            "roofline": {
+                "bound": "hbm", "bytes_per_bp": 5.625,
+                "achieved": 5.625 * n / build_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": 5.625 * n / build_s / 1e9 / HBM_PEAK_GBS,
+            },
+            "stats": {"levels": sa_stats[0], "leaves": sa_stats[1], "unresolved_rows": sa_stats[2],
+                      "doubling_rounds": sa_stats[3]},
+            "kernels_ms": {k: round(v[1] / max(args.build_reps, 1), 4) for k, v in sorted(build_kernels.items())},
+        },
+        "locate": {
+            "value": R / locate_s,
+            "unit": "rows/s",
+            "lf_steps_per_row": lf_steps / max(located, 1),
+            "kernel_ms": loc_ms / max(loc_launch, 1),
+            "achieved_gbs": loc_bytes / (loc_ms * 1e-3) / 1e9 if loc_ms else 0.0,
+        },
+        "search_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(search_kernels.items())},
+        "index_bytes": ix.device_bytes,
+    }
+    if not args.no_cpu and world == 1:
+        gs = G.to_numpy_u32(sp[: args.cpu_reads])
+        ge = G.to_numpy_u32(ep[: args.cpu_reads])
+        result["cpu_baseline"] = cpu_baseline(args, d_text, n, d_reads, R, m, gs, ge)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

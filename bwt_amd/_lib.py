@@ -39,7 +39,16 @@ SIGNATURES = {
     "bwtgpu_index_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
     "bwtgpu_index_export": (C.c_int, [vp, vp, vp]),
     "bwtgpu_index_rank_rows16": (C.c_int, [vp, vp]),
+    "bwtgpu_index_rank_rows": (C.c_int, [vp, u32, vp]),
     "bwtgpu_index_device_bytes": (sz, [vp]),
+    "bwtgpu_occ_batch": (C.c_int, [vp, vp, vp, u64, C.c_int, vp, vp]),
+    "bwtgpu_lf_batch": (C.c_int, [vp, vp, u64, vp, vp]),
+    "bwtgpu_sa_build_host": (C.c_int, [vp, u32, vp]),
+    "bwtgpu_bwt_from_sa_host": (C.c_int, [vp, vp, u32, vp, vp]),
+    "bwtgpu_search_host": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
+    "bwtgpu_locate_rows_host": (C.c_int, [vp, vp, u64, vp]),
+    "bwtgpu_occ_host": (C.c_int, [vp, vp, vp, u64, C.c_int, vp]),
+    "bwtgpu_lf_host": (C.c_int, [vp, vp, u64, vp]),
     "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
     "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),

@@ -90,6 +90,19 @@ struct __attribute__((aligned(32))) IndexBlock {
 };
 static_assert(sizeof(IndexBlock) == 32, "one rank = one 32-byte sector");
 
+// Backward search reads a second, per-symbol layout: for each symbol c an
+// array of 16-byte blocks, block b covering BWT positions [96 b, 96 b + 96):
+//   occ = C[c] + number of c in BWT[0, 96 b)
+//   m   = bit k set iff BWT[96 b + k] == c
+// so C[c] + Occ(c, i) is ONE 16-byte load, a mask and three popcounts, and the
+// two ends of an SA interval share that load whenever they fall in one block.
+struct __attribute__((aligned(16))) SymBlock {
+  uint32_t occ;
+  uint32_t m[3];
+};
+static_assert(sizeof(SymBlock) == 16, "one rank = one 16-byte load");
+constexpr uint32_t kSymBases = 96;
+
 }  // namespace bwtgpu
 
 struct bwtgpu_index {
@@ -98,6 +111,8 @@ struct bwtgpu_index {
   uint32_t C[5] = {0, 0, 0, 0, 0};
   uint64_t nblocks = 0;  // n/64 + 1
   bwtgpu::IndexBlock *d_blocks = nullptr;
+  uint64_t nsym = 0;     // blocks per symbol in d_sym: n/96 + 1
+  bwtgpu::SymBlock *d_sym = nullptr;  // [4][nsym]
   uint32_t *d_idxs = nullptr;  // 1 + n/32 sampled SA rows
   int device = 0;
 };

@@ -8,13 +8,15 @@ namespace bwtgpu {
 // What a kernel needs of an index, passed by value (lives in SGPRs).
 struct IndexView {
   const IndexBlock *blocks;
+  const SymBlock *sym;
   const uint32_t *idxs;
+  uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
 };
 
 inline IndexView view_of(const bwtgpu_index *ix) {
-  return IndexView{ix->d_blocks, ix->d_idxs, ix->n, ix->endloc};
+  return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
@@ -34,6 +36,22 @@ __device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
   const uint64_t lo = b->lo, hi = b->hi;
   const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(idx & 63u);
   return base + (uint32_t)__popcll(match);
+}
+
+// j / 96 and j % 96 for a 32-bit j
+__device__ __forceinline__ uint32_t div96(uint32_t j, uint32_t &rem) {
+  const uint32_t q = __umulhi(j >> 5, 0xAAAAAAABu) >> 1;  // (j / 32) / 3
+  rem = j - q * kSymBases;
+  return q;
+}
+
+// number of set bits among the first r (0..95) bits of a SymBlock mask, plus occ
+__device__ __forceinline__ uint32_t sym_count(const uint4 &b, uint32_t r) {
+  const uint64_t lo64 = ((uint64_t)b.z << 32) | b.y;
+  const bool full = r >= 64;
+  const uint64_t mlo = full ? ~0ull : low_mask(r);
+  const uint32_t mhi = full ? (uint32_t)low_mask(r - 64) : 0u;
+  return b.x + (uint32_t)__popcll(lo64 & mlo) + (uint32_t)__popc(b.w & mhi);
 }
 
 // LF mapping (seqindex.c:214-219) for a row in [0, n].

@@ -1,0 +1,187 @@
+// Host-pointer forms of the device entry points: upload, run the same kernels,
+// download.  These are what the C host layer (bwt_amd/host) calls to stand in
+// for the reference's host functions; the compute is still all on the GPU.
+#include "common.hpp"
+#include "fm_device.hpp"
+
+namespace bwtgpu {
+
+struct Dev {
+  void *p = nullptr;
+  ~Dev() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+// Occ(c, idx) on the packed BWT (no C, no $ adjustment): seq_rank, seqindex.c:91-111
+__global__ void k_occ_batch(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
+                            const uint8_t *__restrict__ cs, const uint32_t *__restrict__ idx,
+                            uint64_t R, int adjust, uint32_t *__restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t c = cs[r] & 3u;
+  uint32_t i = idx[r];
+  if (adjust) i -= (i > v.endloc);  // rank(), seqindex.c:221-225
+  if (i > v.n) {
+    out[r] = 0xFFFFFFFFu;
+    return;
+  }
+  uint32_t rem;
+  const uint32_t b = div96(i, rem);
+  const uint4 blk = reinterpret_cast<const uint4 *>(v.sym)[(uint64_t)c * v.nsym + b];
+  const uint32_t Cc = c == 0 ? C0 : c == 1 ? C1 : c == 2 ? C2 : C3;
+  out[r] = sym_count(blk, rem) - Cc;
+}
+
+__global__ void k_lf_batch(IndexView v, const uint32_t *__restrict__ rows, uint64_t R,
+                           uint32_t *__restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t i = rows[r];
+  out[r] = i > v.n ? 0xFFFFFFFFu : lf_step(v, i);
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+int bwtgpu_occ_batch(const bwtgpu_index *ix, const uint8_t *d_c, const uint32_t *d_idx, uint64_t R,
+                     int skip_dollar_row, uint32_t *d_out, void *stream) {
+  if (!ix || !d_c || !d_idx || !d_out) return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_LAUNCH("occ_batch", k_occ_batch, dim3((unsigned)div_up(R, 256)), dim3(256), 0, (hipStream_t)stream,
+             view_of(ix), ix->C[0], ix->C[1], ix->C[2], ix->C[3], d_c, d_idx, R, skip_dollar_row, d_out);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+int bwtgpu_lf_batch(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R, uint32_t *d_out,
+                    void *stream) {
+  if (!ix || !d_rows || !d_out) return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_LAUNCH("lf_batch", k_lf_batch, dim3((unsigned)div_up(R, 256)), dim3(256), 0, (hipStream_t)stream,
+             view_of(ix), d_rows, R, d_out);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+int bwtgpu_sa_build_host(const uint8_t *h_text, uint32_t n, uint32_t *h_sa) {
+  if (!h_text || !h_sa || n == 0) return set_error(kErrArg, "bad argument");
+  Dev text, sa, ws;
+  const size_t nbytes = (size_t)n / 4 + 1, wsb = bwtgpu_sa_workspace_bytes(n);
+  hipError_t e = text.alloc(nbytes + 64);
+  if (e == hipSuccess) e = sa.alloc(((size_t)n + 1) * 4);
+  if (e == hipSuccess) e = ws.alloc(wsb);
+  if (e != hipSuccess) return set_error(kErrHip, "SA buffers for n=%u: %s", n, hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(text.p, h_text, nbytes, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_sa_build(text.as<uint8_t>(), n, sa.as<uint32_t>(), ws.p, wsb, nullptr));
+  BWT_HIP(hipMemcpy(h_sa, sa.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+  return kOk;
+}
+
+int bwtgpu_bwt_from_sa_host(const uint8_t *h_text, const uint32_t *h_sa, uint32_t n, uint8_t *h_bwt,
+                            uint32_t *endloc) {
+  if (!h_text || !h_sa || !h_bwt || !endloc || n == 0) return set_error(kErrArg, "bad argument");
+  Dev text, sa, bwt, e4;
+  const size_t nbytes = (size_t)n / 4 + 1, nb = ((size_t)n + 3) / 4;
+  hipError_t e = text.alloc(nbytes + 64);
+  if (e == hipSuccess) e = sa.alloc(((size_t)n + 1) * 4);
+  if (e == hipSuccess) e = bwt.alloc(nb + 64);
+  if (e == hipSuccess) e = e4.alloc(256);
+  if (e != hipSuccess) return set_error(kErrHip, "BWT buffers for n=%u: %s", n, hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(text.p, h_text, nbytes, hipMemcpyHostToDevice));
+  BWT_HIP(hipMemcpy(sa.p, h_sa, ((size_t)n + 1) * 4, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_bwt_from_sa(text.as<uint8_t>(), sa.as<uint32_t>(), n, bwt.as<uint8_t>(),
+                             e4.as<uint32_t>(), nullptr));
+  BWT_HIP(hipMemcpy(h_bwt, bwt.p, nb, hipMemcpyDeviceToHost));
+  BWT_HIP(hipMemcpy(endloc, e4.p, 4, hipMemcpyDeviceToHost));
+  if (*endloc > n) return set_error(kErrArg, "the array holds no row for suffix 0");
+  return kOk;
+}
+
+// Reads on the host, results to the host; batches are cut to bound device memory.
+int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride,
+                       uint64_t R, uint32_t *h_sp, uint32_t *h_ep, uint32_t *h_locrow, uint32_t *h_pos) {
+  if (!ix || !h_pats || m == 0) return set_error(kErrArg, "bad argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint64_t chunk_max = stride ? (1ull << 30) / (stride > m ? stride : m) + 1 : R;
+  const uint64_t chunk = R < chunk_max ? R : chunk_max;
+  Dev pats, sp, ep, lr, pos, ws, lws;
+  const size_t wsb = bwtgpu_search_workspace_bytes(chunk, m);
+  hipError_t e = pats.alloc((chunk - 1) * stride + m + 64);
+  if (e == hipSuccess) e = sp.alloc(chunk * 4);
+  if (e == hipSuccess) e = ep.alloc(chunk * 4);
+  if (e == hipSuccess) e = lr.alloc(chunk * 4);
+  if (e == hipSuccess) e = pos.alloc(chunk * 4);
+  if (e == hipSuccess) e = ws.alloc(wsb);
+  if (e == hipSuccess) e = lws.alloc(bwtgpu_locate_workspace_bytes());
+  if (e != hipSuccess) return set_error(kErrHip, "search buffers: %s", hipGetErrorString(e));
+  for (uint64_t r0 = 0; r0 < R; r0 += chunk) {
+    const uint64_t cnt = R - r0 < chunk ? R - r0 : chunk;
+    BWT_HIP(hipMemcpy(pats.p, h_pats + r0 * stride, (cnt - 1) * stride + m, hipMemcpyHostToDevice));
+    BWT_TRY(bwtgpu_search(ix, pats.as<uint8_t>(), m, stride, cnt, sp.as<uint32_t>(), ep.as<uint32_t>(),
+                          (h_pos || h_locrow) ? lr.as<uint32_t>() : nullptr, ws.p, wsb, nullptr));
+    if (h_pos)
+      BWT_TRY(bwtgpu_locate_rows(ix, lr.as<uint32_t>(), cnt, pos.as<uint32_t>(), nullptr, lws.p,
+                                 bwtgpu_locate_workspace_bytes(), nullptr));
+    if (h_sp) BWT_HIP(hipMemcpy(h_sp + r0, sp.p, cnt * 4, hipMemcpyDeviceToHost));
+    if (h_ep) BWT_HIP(hipMemcpy(h_ep + r0, ep.p, cnt * 4, hipMemcpyDeviceToHost));
+    if (h_locrow) BWT_HIP(hipMemcpy(h_locrow + r0, lr.p, cnt * 4, hipMemcpyDeviceToHost));
+    if (h_pos) BWT_HIP(hipMemcpy(h_pos + r0, pos.p, cnt * 4, hipMemcpyDeviceToHost));
+  }
+  return kOk;
+}
+
+int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R,
+                            uint32_t *h_pos) {
+  if (!ix || !h_rows || !h_pos) return set_error(kErrArg, "bad argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  Dev rows, pos, lws;
+  hipError_t e = rows.alloc(R * 4);
+  if (e == hipSuccess) e = pos.alloc(R * 4);
+  if (e == hipSuccess) e = lws.alloc(bwtgpu_locate_workspace_bytes());
+  if (e != hipSuccess) return set_error(kErrHip, "locate buffers: %s", hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(rows.p, h_rows, R * 4, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_locate_rows(ix, rows.as<uint32_t>(), R, pos.as<uint32_t>(), nullptr, lws.p,
+                             bwtgpu_locate_workspace_bytes(), nullptr));
+  BWT_HIP(hipMemcpy(h_pos, pos.p, R * 4, hipMemcpyDeviceToHost));
+  return kOk;
+}
+
+int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *h_idx, uint64_t R,
+                    int skip_dollar_row, uint32_t *h_out) {
+  if (!ix || !h_c || !h_idx || !h_out) return set_error(kErrArg, "bad argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  Dev c, idx, out;
+  hipError_t e = c.alloc(R);
+  if (e == hipSuccess) e = idx.alloc(R * 4);
+  if (e == hipSuccess) e = out.alloc(R * 4);
+  if (e != hipSuccess) return set_error(kErrHip, "rank buffers: %s", hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(c.p, h_c, R, hipMemcpyHostToDevice));
+  BWT_HIP(hipMemcpy(idx.p, h_idx, R * 4, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_occ_batch(ix, c.as<uint8_t>(), idx.as<uint32_t>(), R, skip_dollar_row,
+                           out.as<uint32_t>(), nullptr));
+  BWT_HIP(hipMemcpy(h_out, out.p, R * 4, hipMemcpyDeviceToHost));
+  return kOk;
+}
+
+int bwtgpu_lf_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R, uint32_t *h_out) {
+  if (!ix || !h_rows || !h_out) return set_error(kErrArg, "bad argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  Dev rows, out;
+  hipError_t e = rows.alloc(R * 4);
+  if (e == hipSuccess) e = out.alloc(R * 4);
+  if (e != hipSuccess) return set_error(kErrHip, "lf buffers: %s", hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(rows.p, h_rows, R * 4, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_lf_batch(ix, rows.as<uint32_t>(), R, out.as<uint32_t>(), nullptr));
+  BWT_HIP(hipMemcpy(h_out, out.p, R * 4, hipMemcpyDeviceToHost));
+  return kOk;
+}
+
+}  // extern "C"

@@ -223,11 +223,11 @@ __global__ void k_planes_to_bwt(const IndexBlock *__restrict__ blocks, uint64_t 
 
 // Reference-layout rank rows (seqindex.c:23-87, blocksize 16): row j holds the
 // counts of each base in BWT[0, min(16 j, n)).
-__global__ void k_rank_rows16(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
-                              uint64_t rows, uint4 *__restrict__ out) {
+__global__ void k_rank_rows(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
+                            uint32_t blocksize, uint64_t rows, uint4 *__restrict__ out) {
   uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= rows) return;
-  uint64_t p = j * 16;
+  uint64_t p = j * blocksize;
   if (p > v.n) p = v.n;
   const IndexBlock *b = v.blocks + (p >> 6);
   uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
@@ -240,14 +240,60 @@ __global__ void k_rank_rows16(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2
   out[j] = r;
 }
 
+// Per-symbol search blocks from the finished 64-base blocks: one thread per
+// 96-base block, all four symbols.
+__global__ void k_build_sym(const IndexBlock *__restrict__ blocks, uint64_t nblocks, uint32_t n,
+                            SymBlock *__restrict__ sym, uint64_t nsym) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nsym) return;
+  const uint64_t p0 = b * kSymBases;
+  const uint64_t q = p0 >> 6;
+  const uint32_t off = (uint32_t)(p0 & 63u);  // 0 or 32
+  const IndexBlock A = blocks[q];  // q <= n/64 always exists
+  uint64_t lo_b = 0, hi_b = 0;
+  if (q + 1 < nblocks) {
+    lo_b = blocks[q + 1].lo;
+    hi_b = blocks[q + 1].hi;
+  }
+  // 96 plane bits starting at p0
+  uint64_t lo64, hi64;
+  uint32_t lo32, hi32;
+  if (off == 0) {
+    lo64 = A.lo; hi64 = A.hi;
+    lo32 = (uint32_t)lo_b; hi32 = (uint32_t)hi_b;
+  } else {
+    lo64 = (A.lo >> 32) | (lo_b << 32); hi64 = (A.hi >> 32) | (hi_b << 32);
+    lo32 = (uint32_t)(lo_b >> 32); hi32 = (uint32_t)(hi_b >> 32);
+  }
+  const uint64_t valid = p0 >= n ? 0 : (n - p0 >= kSymBases ? kSymBases : n - p0);
+  const uint64_t v64 = valid >= 64 ? ~0ull : ((1ull << valid) - 1ull);
+  const uint32_t v32 = valid >= 96 ? ~0u : (valid > 64 ? ((1u << (valid - 64)) - 1u) : 0u);
+  const uint64_t before = low_mask(off);  // bases of block q that precede p0
+  const uint32_t occq[4] = {A.occ[0], A.occ[1], A.occ[2], A.occ[3]};
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) {
+    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+    const uint64_t m64 = (lo64 ^ nlo) & (hi64 ^ nhi) & v64;
+    const uint32_t m32 = (lo32 ^ (uint32_t)nlo) & (hi32 ^ (uint32_t)nhi) & v32;
+    SymBlock o;
+    o.occ = occq[c] + (uint32_t)__popcll((A.lo ^ nlo) & (A.hi ^ nhi) & before);
+    o.m[0] = (uint32_t)m64;
+    o.m[1] = (uint32_t)(m64 >> 32);
+    o.m[2] = m32;
+    sym[(uint64_t)c * nsym + b] = o;
+  }
+}
+
 int index_alloc(bwtgpu_index **out, uint32_t n) {
   if (n == 0 || n > 0xFFFFFFF0u)
     return set_error(kErrArg, "text length %u out of range", n);
   bwtgpu_index *ix = new bwtgpu_index();
   ix->n = n;
   ix->nblocks = (uint64_t)n / 64 + 1;
+  ix->nsym = (uint64_t)n / kSymBases + 1;
   BWT_HIP(hipGetDevice(&ix->device));
   hipError_t e = hipMalloc(&ix->d_blocks, ix->nblocks * sizeof(IndexBlock));
+  if (e == hipSuccess) e = hipMalloc(&ix->d_sym, 4 * ix->nsym * sizeof(SymBlock));
   if (e == hipSuccess) e = hipMalloc(&ix->d_idxs, ((uint64_t)n / 32 + 1) * sizeof(uint32_t));
   if (e != hipSuccess) {
     bwtgpu_index_free(ix);
@@ -270,6 +316,8 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
   BWT_LAUNCH("rank_scan_tiles", k_rank_scan_tiles, dim3(1), dim3(1024), 0, s, d_tiles, ntiles, d_C);
   BWT_LAUNCH("rank_apply", k_rank_apply, dim3(ntiles), dim3(kTileThreads), 0, s, ix->d_blocks, nb,
              ix->n, d_tiles);
+  BWT_LAUNCH("rank_build_sym", k_build_sym, dim3((unsigned)div_up(ix->nsym, 256)), dim3(256), 0, s,
+             ix->d_blocks, nb, ix->n, ix->d_sym, ix->nsym);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -289,6 +337,7 @@ extern "C" {
 void bwtgpu_index_free(bwtgpu_index *ix) {
   if (!ix) return;
   if (ix->d_blocks) (void)hipFree(ix->d_blocks);
+  if (ix->d_sym) (void)hipFree(ix->d_sym);
   if (ix->d_idxs) (void)hipFree(ix->d_idxs);
   delete ix;
 }
@@ -296,7 +345,7 @@ void bwtgpu_index_free(bwtgpu_index *ix) {
 bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t endloc,
                                       const uint32_t *h_idxs, void *stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (!h_bwt || !h_idxs) {
+  if (!h_bwt) {
     set_error(kErrArg, "null input");
     return nullptr;
   }
@@ -321,7 +370,8 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
   e = hipMemsetAsync(d_bwt, 0, nb * 16, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_bwt, h_bwt, bwt_bytes, hipMemcpyHostToDevice, s);
   if (e == hipSuccess)
-    e = hipMemcpyAsync(ix->d_idxs, h_idxs, ((size_t)n / 32 + 1) * 4, hipMemcpyHostToDevice, s);
+    e = h_idxs ? hipMemcpyAsync(ix->d_idxs, h_idxs, ((size_t)n / 32 + 1) * 4, hipMemcpyHostToDevice, s)
+               : hipMemsetAsync(ix->d_idxs, 0, ((size_t)n / 32 + 1) * 4, s);
   if (e != hipSuccess) return fail(e, "index upload");
   {
     ScopedKernelTimer t("bwt_to_planes", s);
@@ -348,7 +398,8 @@ int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc, uin
 
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
-  return ix->nblocks * sizeof(IndexBlock) + ((size_t)ix->n / 32 + 1) * 4;
+  return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
+         ((size_t)ix->n / 32 + 1) * 4;
 }
 
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {
@@ -371,13 +422,18 @@ int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs
 }
 
 int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows) {
+  return bwtgpu_index_rank_rows(ix, 16, h_rows);
+}
+
+int bwtgpu_index_rank_rows(const bwtgpu_index *ix, uint32_t blocksize, uint32_t *h_rows) {
   if (!ix || !h_rows) return set_error(kErrArg, "null argument");
+  if (blocksize == 0 || blocksize % 4) return set_error(kErrArg, "blocksize must be a multiple of 4");
   BWT_HIP(hipSetDevice(ix->device));
-  const uint64_t rows = 1 + ((uint64_t)ix->n + 15) / 16;
+  const uint64_t rows = 1 + ((uint64_t)ix->n + blocksize - 1) / blocksize;
   uint4 *d_rows = nullptr;
   BWT_HIP(hipMalloc(&d_rows, rows * 16));
-  BWT_LAUNCH("rank_rows16", k_rank_rows16, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, nullptr,
-             view_of(ix), ix->C[0], ix->C[1], ix->C[2], ix->C[3], rows, d_rows);
+  BWT_LAUNCH("rank_rows", k_rank_rows, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, nullptr,
+             view_of(ix), ix->C[0], ix->C[1], ix->C[2], ix->C[3], blocksize, rows, d_rows);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(h_rows, d_rows, rows * 16, hipMemcpyDeviceToHost);
   (void)hipFree(d_rows);

@@ -1,8 +1,10 @@
 // FM-index backward search and locate: one read per lane, index resident in HBM.
 //
-// Per read of m bases the search touches 2(m-1) index blocks (one 32-byte
-// sector each) and its own m/4 bytes of packed pattern; locate adds one block
-// per LF step.  Both kernels are bound by random 32-byte HBM/L2 reads.
+// Per read of m bases the search makes 2(m-1) rank queries, each one 16-byte
+// load from the per-symbol layout (the two ends of an interval share the load
+// once the interval is narrow), and reads its own m/4 bytes of packed pattern;
+// locate adds one 32-byte block per LF step.  Both kernels are bound by the
+// rate of random small reads (vector L1 lookups, then L2 / Infinity Cache / HBM).
 #include "common.hpp"
 #include "fm_device.hpp"
 
@@ -86,15 +88,20 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
       break;
     }
     c = (word >> (2 * (i & 15))) & 3u;
-    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
-    const uint32_t nsp = occ_c(v, c, nlo, nhi, sp);
-    const uint32_t nep = occ_c(v, c, nlo, nhi, ep);
-    sp = nsp;
-    ep = nep;
+    // rank() first steps over the unstored $ row (seqindex.c:222-223)
+    const uint32_t js = sp - (sp > v.endloc), je = ep - (ep > v.endloc);
+    uint32_t rs, re;
+    const uint32_t bs = div96(js, rs), be = div96(je, re);
+    const uint4 *col = reinterpret_cast<const uint4 *>(v.sym) + (uint64_t)c * v.nsym;
+    const uint4 blk_s = col[bs];
+    uint4 blk_e = blk_s;
+    if (be != bs) blk_e = col[be];  // narrow intervals share the block
+    sp = sym_count(blk_s, rs);
+    ep = sym_count(blk_e, re);
   }
   d_sp[r] = sp;
   d_ep[r] = ep;
-  if (d_locrow) d_locrow[r] = (early || sp > v.n) ? 0xFFFFFFFFu : sp;
+  if (d_locrow) d_locrow[r] = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
 }
 
 constexpr uint32_t kLocateBatch = 256;  // rows a wave takes from the queue at a time

@@ -1,0 +1,492 @@
+/*
+ * The reference's C API (histsortcomp.h, csacak.h, seqindex.h, fileio.h) over
+ * the HIP kernels of libbwt_mi355x.so.  Every function here hands its work to
+ * a device entry point of bwt_gpu.h; there is no host implementation of the
+ * algorithms to fall back on.  When the device call fails the error goes to
+ * stderr and the function returns the reference's failure value.
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bwt_gpu.h"
+#include "bwt_mi355x.h"
+
+/* ------------------------------------------------------------------ */
+/* device selection and the fm_index -> device index registry          */
+/* ------------------------------------------------------------------ */
+
+static int device_ready(void) {
+  /* every host thread that enters the API makes the device current */
+  const char *env = getenv("BWT_MI355X_DEVICE");
+  int dev = env ? atoi(env) : 0;
+  int rc = bwtgpu_init(dev);
+  if (rc) fprintf(stderr, "bwt_mi355x: %s\n", bwtgpu_last_error());
+  return rc;
+}
+
+static void report(const char *what) {
+  fprintf(stderr, "bwt_mi355x: %s: %s\n", what, bwtgpu_last_error());
+}
+
+struct reg_entry {
+  const fm_index *fmi;
+  bwtgpu_index *ix;
+  int *rank_slab; /* rows of rank_index, one allocation */
+  struct reg_entry *next;
+};
+static struct reg_entry *g_reg;
+static pthread_mutex_t g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
+
+static void reg_put(const fm_index *fmi, bwtgpu_index *ix, int *rank_slab) {
+  struct reg_entry *e = malloc(sizeof *e);
+  e->fmi = fmi;
+  e->ix = ix;
+  e->rank_slab = rank_slab;
+  pthread_mutex_lock(&g_reg_lock);
+  e->next = g_reg;
+  g_reg = e;
+  pthread_mutex_unlock(&g_reg_lock);
+}
+
+static struct reg_entry *reg_find_locked(const fm_index *fmi) {
+  for (struct reg_entry *e = g_reg; e; e = e->next)
+    if (e->fmi == fmi) return e;
+  return NULL;
+}
+
+/* The device index behind an fm_index.  One that did not come from make_fmi
+ * or read_index (a caller filled the struct itself) is uploaded on first use
+ * from its stored parts, as read_index would. */
+static bwtgpu_index *device_index(const fm_index *fmi) {
+  if (!fmi) return NULL;
+  pthread_mutex_lock(&g_reg_lock);
+  struct reg_entry *e = reg_find_locked(fmi);
+  bwtgpu_index *ix = e ? e->ix : NULL;
+  pthread_mutex_unlock(&g_reg_lock);
+  if (ix) return device_ready() ? NULL : ix;
+  if (device_ready()) return NULL;
+  ix = bwtgpu_index_from_parts((const uint8_t *)fmi->bwt, (uint32_t)fmi->len, (uint32_t)fmi->endloc,
+                               (const uint32_t *)fmi->idxs, NULL);
+  if (!ix) {
+    report("index upload");
+    return NULL;
+  }
+  reg_put(fmi, ix, NULL);
+  return ix;
+}
+
+/* ------------------------------------------------------------------ */
+/* suffix array and BWT (histsortcomp.h, csacak.h)                     */
+/* ------------------------------------------------------------------ */
+
+static uint32_t *sa_on_device(const char *str, uint32_t len) {
+  if (device_ready()) return NULL;
+  uint32_t *sa = malloc(((size_t)len + 1) * sizeof *sa);
+  if (!sa) return NULL;
+  if (bwtgpu_sa_build_host((const uint8_t *)str, len, sa)) {
+    report("suffix array");
+    free(sa);
+    return NULL;
+  }
+  return sa;
+}
+
+int *histsort(const char *str, int len) { return (int *)sa_on_device(str, (uint32_t)len); }
+
+unsigned int *csuff_arr(const char *seq, unsigned int len) { return sa_on_device(seq, len); }
+
+unsigned int sprintcbwt(const char *str, unsigned int *idxs, unsigned int len, char *out) {
+  uint32_t endloc = 0xFFFFFFFFu;
+  if (device_ready()) return endloc;
+  if (bwtgpu_bwt_from_sa_host((const uint8_t *)str, idxs, len, (uint8_t *)out, &endloc))
+    report("BWT");
+  return endloc;
+}
+
+int makecbwt(const char *str, int len, char *out) {
+  /* histsortcomp.c:195-201 */
+  int *sa = histsort(str, len);
+  if (!sa) return -1;
+  int e = (int)sprintcbwt(str, (unsigned int *)sa, (unsigned int)len, out);
+  free(sa);
+  return e;
+}
+
+int saca_makecbwt(const char *str, int len, char *out) {
+  /* histsortcomp.c:204-210: same array, so same call */
+  return makecbwt(str, len, out);
+}
+
+static unsigned base_at(const char *s, long i) {
+  return ((unsigned char)s[i >> 2] >> (2 * (3 - (i & 3)))) & 3u;
+}
+
+void sprintbwt(char *out, const char *str, const int *bwt, int len) {
+  /* histsortcomp.c:267-275: len is the length of the BWT; the last row is not printed */
+  int i;
+  for (i = 0; i != len; ++i) out[i] = bwt[i] ? (char)('0' + base_at(str, (long)bwt[i] - 1)) : '$';
+  out[i] = 0;
+}
+
+char *makebwt(const char *str, int len) {
+  /* histsortcomp.c:183-191 */
+  int *sa = histsort(str, len);
+  if (!sa) return NULL;
+  char *buf = malloc((size_t)len + 2);
+  sprintbwt(buf, str, sa, len);
+  free(sa);
+  return buf;
+}
+
+void putbwt(const char *str, const int *bwt, int len) {
+  /* histsortcomp.c:277-287 */
+  for (int i = 0; i <= len; ++i) putchar(bwt[i] ? (int)('0' + base_at(str, (long)bwt[i] - 1)) : '$');
+  putchar('\n');
+}
+
+void putsg(const char *str, int idx, int len) {
+  /* histsortcomp.c:252-265 */
+  printf("%3d: ", idx);
+  for (int i = idx; i != len; ++i) putchar((int)('0' + base_at(str, i)));
+  putchar('$');
+  for (int i = 0; i != idx; ++i) putchar((int)('0' + base_at(str, i)));
+  putchar('\n');
+}
+
+void printseq(const char *seq, int startidx, int len) {
+  /* seqindex.c:354-360 */
+  for (int i = 0; i < len; ++i) putchar("ACGT"[base_at(seq, (long)startidx + i)]);
+  putchar('\n');
+}
+
+/* ------------------------------------------------------------------ */
+/* FM-index construction (seqindex.h)                                  */
+/* ------------------------------------------------------------------ */
+
+unsigned char *lookup_table(void) {
+  /* seqindex.c:115-138: tbl[4*b + c] = how often base c occurs in byte b.
+   * A constant table; kept because fm_index carries a pointer to one. */
+  unsigned char *tbl = calloc(1024, 1);
+  for (unsigned b = 0; b < 256; ++b)
+    for (unsigned k = 0; k < 4; ++k) tbl[4 * b + ((b >> (2 * k)) & 3u)]++;
+  return tbl;
+}
+
+/* rows of the reference's rank table, computed on device */
+static int **rank_rows_from_device(const bwtgpu_index *ix, uint32_t len, uint32_t blocksize,
+                                   int **slab_out) {
+  size_t rows = 1 + ((size_t)len + blocksize - 1) / blocksize;
+  int *slab = malloc(rows * 4 * sizeof *slab);
+  int **index = malloc(rows * sizeof *index);
+  if (!slab || !index || bwtgpu_index_rank_rows(ix, blocksize, (uint32_t *)slab)) {
+    report("rank rows");
+    free(slab);
+    free(index);
+    return NULL;
+  }
+  for (size_t j = 0; j < rows; ++j) index[j] = slab + 4 * j;
+  if (slab_out) *slab_out = slab;
+  return index;
+}
+
+int **seq_index(char *bwt, int len, int blocksize, const unsigned char *tbl) {
+  /* seqindex.c:23-87.  The rows live in one allocation whose address is
+   * index[0]; free(index[0]); free(index) releases them. */
+  (void)tbl;
+  if (device_ready()) return NULL;
+  bwtgpu_index *ix = bwtgpu_index_from_parts((const uint8_t *)bwt, (uint32_t)len, 0, NULL, NULL);
+  if (!ix) {
+    report("seq_index");
+    return NULL;
+  }
+  int **index = rank_rows_from_device(ix, (uint32_t)len, (uint32_t)blocksize, NULL);
+  bwtgpu_index_free(ix);
+  return index;
+}
+
+int seq_rank(unsigned char *bwt, int **sidx, int blocksize, int idx, char c,
+             const unsigned char *lookup) {
+  /* seqindex.c:91-111: reads a caller-owned table, nothing to offload */
+  unsigned u = (unsigned)idx;
+  int x = sidx[u / (unsigned)blocksize][(int)c];
+  for (unsigned i = (u / (unsigned)blocksize) * (unsigned)blocksize / 4; i < u / 4; i++)
+    x += lookup[4 * bwt[i] + c];
+  for (unsigned i = 0; i < u % 4; ++i)
+    if (base_at((const char *)bwt, (long)((u & ~3u) + i)) == (unsigned)c) ++x;
+  return x;
+}
+
+void destroy_fmi(fm_index *fmi) {
+  /* seqindex.c:140-157 */
+  if (!fmi) return;
+  pthread_mutex_lock(&g_reg_lock);
+  struct reg_entry **pp = &g_reg, *e = NULL;
+  while (*pp && (*pp)->fmi != fmi) pp = &(*pp)->next;
+  if (*pp) {
+    e = *pp;
+    *pp = e->next;
+  }
+  pthread_mutex_unlock(&g_reg_lock);
+  if (e) {
+    bwtgpu_index_free(e->ix);
+    if (e->rank_slab) {
+      free(e->rank_slab);
+      free(fmi->rank_index);
+      fmi->rank_index = NULL;
+    }
+    free(e);
+  }
+  if (fmi->rank_index) {
+    /* a table made by seq_index: rows are one allocation at index[0] */
+    free(fmi->rank_index[0]);
+    free(fmi->rank_index);
+  }
+  free(fmi->bwt);
+  free(fmi->idxs);
+  free(fmi->lookup);
+  free(fmi);
+}
+
+/* host-side fields of an fm_index whose device index exists */
+static fm_index *wrap_device_index(bwtgpu_index *ix, int need_export) {
+  fm_index *fmi = calloc(1, sizeof *fmi);
+  uint32_t n, endloc, C[5];
+  bwtgpu_index_info(ix, &n, &endloc, C);
+  fmi->len = (int)n;
+  fmi->endloc = (int)endloc;
+  for (int i = 0; i < 5; ++i) fmi->C[i] = (int)C[i];
+  if (need_export) {
+    fmi->bwt = malloc(((size_t)n + 3) / 4 + 1);
+    fmi->idxs = malloc(((size_t)n / 32 + 1) * sizeof(int));
+    if (bwtgpu_index_export(ix, (uint8_t *)fmi->bwt, (uint32_t *)fmi->idxs)) {
+      report("index export");
+      free(fmi->bwt);
+      free(fmi->idxs);
+      free(fmi);
+      return NULL;
+    }
+  }
+  return fmi;
+}
+
+static void attach_tables(fm_index *fmi, bwtgpu_index *ix) {
+  int *slab = NULL;
+  fmi->lookup = lookup_table();
+  /* above 2^28 bases the reference's own rows are wrong (seqindex.c:78) and
+   * the table would take gigabytes of host memory; the device blocks serve */
+  if ((uint32_t)fmi->len < (1u << 28))
+    fmi->rank_index = rank_rows_from_device(ix, (uint32_t)fmi->len, 16, &slab);
+  reg_put(fmi, ix, slab);
+}
+
+fm_index *make_fmi(const char *str, int len) {
+  /* seqindex.c:161-189 */
+  if (device_ready()) return NULL;
+  bwtgpu_index *ix = bwtgpu_index_build((const uint8_t *)str, (uint32_t)len, NULL);
+  if (!ix) {
+    report("make_fmi");
+    return NULL;
+  }
+  fm_index *fmi = wrap_device_index(ix, 1);
+  if (!fmi) {
+    bwtgpu_index_free(ix);
+    return NULL;
+  }
+  attach_tables(fmi, ix);
+  return fmi;
+}
+
+fm_index *make_fmi_sacak(const char *str, int len) {
+  /* seqindex.c:192-212: differs from make_fmi only in the SA routine, and the
+   * device build already takes any input */
+  return make_fmi(str, len);
+}
+
+/* ------------------------------------------------------------------ */
+/* index file (fileio.h)                                               */
+/* ------------------------------------------------------------------ */
+
+void write_index(const fm_index *fmi, FILE *f) {
+  /* fileio.c:8-18 */
+  uint32_t n = (uint32_t)fmi->len;
+  fwrite(&fmi->len, sizeof(int), 1, f);
+  fwrite(fmi->C, sizeof(int), 5, f);
+  fwrite(&fmi->endloc, sizeof(int), 1, f);
+  fwrite(fmi->idxs, sizeof(int), 1 + (size_t)n / 32, f);
+  fwrite(fmi->bwt, 1, ((size_t)n + 3) / 4, f);
+}
+
+fm_index *read_index(const char *seq, FILE *f) {
+  /* fileio.c:24-65; `seq` is unused there too */
+  (void)seq;
+  int err = 0;
+  fm_index *fmi = calloc(1, sizeof *fmi);
+  if (fread(&fmi->len, sizeof(int), 1, f) != 1) err = 1;
+  if (!err && fread(fmi->C, sizeof(int), 5, f) != 5) err = 1;
+  if (!err && fread(&fmi->endloc, sizeof(int), 1, f) != 1) err = 1;
+  if (!err) {
+    uint32_t n = (uint32_t)fmi->len;
+    size_t ns = 1 + (size_t)n / 32, nb = ((size_t)n + 3) / 4;
+    fmi->idxs = malloc(ns * sizeof(int));
+    fmi->bwt = malloc(nb + 1);
+    if (!fmi->idxs || !fmi->bwt || fread(fmi->idxs, sizeof(int), ns, f) != ns ||
+        fread(fmi->bwt, 1, nb, f) != nb)
+      err = 1;
+  }
+  if (err) {
+    fprintf(stderr, "Error reading index from file\n");
+    free(fmi->bwt);
+    free(fmi->idxs);
+    free(fmi);
+    return NULL;
+  }
+  /* the rank table is not stored; the reference rebuilds it on the host
+   * (fileio.c:62-63), here the device rebuilds its blocks */
+  bwtgpu_index *ix = NULL;
+  if (!device_ready())
+    ix = bwtgpu_index_from_parts((const uint8_t *)fmi->bwt, (uint32_t)fmi->len,
+                                 (uint32_t)fmi->endloc, (const uint32_t *)fmi->idxs, NULL);
+  if (!ix) {
+    report("read_index");
+    free(fmi->bwt);
+    free(fmi->idxs);
+    free(fmi);
+    return NULL;
+  }
+  attach_tables(fmi, ix);
+  return fmi;
+}
+
+/* ------------------------------------------------------------------ */
+/* queries (seqindex.h): single calls are batches of one               */
+/* ------------------------------------------------------------------ */
+
+int rank(const fm_index *fmi, char c, int idx) {
+  bwtgpu_index *ix = device_index(fmi);
+  uint8_t cc = (uint8_t)c;
+  uint32_t i = (uint32_t)idx, out = 0;
+  if (!ix || bwtgpu_occ_host(ix, &cc, &i, 1, 1, &out)) {
+    if (ix) report("rank");
+    return -1;
+  }
+  return (int)out;
+}
+
+int lf(const fm_index *fmi, int idx) {
+  bwtgpu_index *ix = device_index(fmi);
+  uint32_t i = (uint32_t)idx, out = 0;
+  if (!ix || bwtgpu_lf_host(ix, &i, 1, &out)) {
+    if (ix) report("lf");
+    return -1;
+  }
+  return (int)out;
+}
+
+int unc_sa(const fm_index *fmi, int idx) {
+  int pos = -1;
+  fmi_unc_sa_batch(fmi, &idx, 1, &pos);
+  return pos;
+}
+
+void loc_search(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep) {
+  fmi_search_batch(fmi, pattern, len, len, 1, sp, ep);
+}
+
+int reverse_search(const fm_index *fmi, const char *pattern, int len) {
+  int r = 0;
+  fmi_reverse_search_batch(fmi, pattern, len, len, 1, &r);
+  return r;
+}
+
+int locate(const fm_index *fmi, const char *pattern, int len) {
+  bwtgpu_index *ix = device_index(fmi);
+  uint32_t sp, ep, row, pos;
+  if (!ix || bwtgpu_search_host(ix, (const uint8_t *)pattern, (uint32_t)len, (uint64_t)len, 1, &sp, &ep,
+                                &row, &pos)) {
+    if (ix) report("locate");
+    return -1;
+  }
+  if (row == 0xFFFFFFFFu) return -1; /* seqindex.c:268-270 */
+  if (ep - sp != 1) printf("Warning: multiple matches found (returned first)\n"); /* seqindex.c:274-275 */
+  return (int)pos;
+}
+
+/* ------------------------------------------------------------------ */
+/* batch forms                                                         */
+/* ------------------------------------------------------------------ */
+
+int fmi_search_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                     int *sp, int *ep) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
+                         (uint32_t *)sp, (uint32_t *)ep, NULL, NULL)) {
+    report("search");
+    return -1;
+  }
+  return 0;
+}
+
+int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                             long nreads, int *result) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  uint32_t *sp = malloc((size_t)nreads * 4), *ep = malloc((size_t)nreads * 4);
+  int rc = -1;
+  /* result doubles as the buffer for the locate rows, which say whether the
+   * interval emptied before the last step */
+  if (sp && ep &&
+      !bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads, sp,
+                          ep, (uint32_t *)result, NULL)) {
+    for (long r = 0; r < nreads; ++r) /* seqindex.c:233-241 */
+      result[r] = (uint32_t)result[r] == 0xFFFFFFFFu ? 0 : (int)(ep[r] - sp[r] + 1);
+    rc = 0;
+  } else {
+    report("reverse_search");
+  }
+  free(sp);
+  free(ep);
+  return rc;
+}
+
+int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                     int *pos) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
+                         NULL, NULL, NULL, (uint32_t *)pos)) {
+    report("locate");
+    return -1;
+  }
+  return 0; /* 0xFFFFFFFF reads as -1 */
+}
+
+int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_locate_rows_host(ix, (const uint32_t *)rows, (uint64_t)nrows, (uint32_t *)pos)) {
+    report("unc_sa");
+    return -1;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* genome packer                                                       */
+/* ------------------------------------------------------------------ */
+
+void fmi_pack_ascii(const char *ascii, long len, char *out) {
+  /* build_index.c:54-77: exact-case C, G, T; everything else, and everything
+   * past the end of the file, is A */
+  static const unsigned char code[256] = {['C'] = 1, ['G'] = 2, ['T'] = 3};
+  long full = len / 4;
+  for (long i = 0; i < full; ++i) {
+    const unsigned char *p = (const unsigned char *)ascii + 4 * i;
+    out[i] = (char)(code[p[0]] << 6 | code[p[1]] << 4 | code[p[2]] << 2 | code[p[3]]);
+  }
+  /* build_index.c:80-87: the tail loop's test is (i < len) & 3 and its reads
+   * all hit end of file, so it leaves the byte of the last len%4 bases zero */
+  out[full] = 0;
+}

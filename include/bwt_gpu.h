@@ -69,7 +69,8 @@ bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream
 /* Same from a packed text already in HBM. */
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream);
 /* Replaces the rebuild half of read_index (fileio.c:44-63): takes the stored
- * parts of an index (host pointers) and rebuilds the rank blocks on device. */
+ * parts of an index (host pointers) and rebuilds the rank blocks on device.
+ * h_idxs may be NULL (no locate on such an index). */
 bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n,
                                       uint32_t endloc, const uint32_t *h_idxs,
                                       void *stream);
@@ -82,6 +83,9 @@ int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs
 /* Rank rows in the reference's layout (seq_index, seqindex.c:23-87, blocksize
  * 16): 1+(n+15)/16 rows of 4 counts, computed on device, copied to h_rows. */
 int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows);
+/* Same for any blocksize that is a multiple of 4 (seq_index's third argument):
+ * 1+(n+blocksize-1)/blocksize rows. */
+int bwtgpu_index_rank_rows(const bwtgpu_index *ix, uint32_t blocksize, uint32_t *h_rows);
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
 
 /* ---- backward search (HP2) ---- */
@@ -92,7 +96,8 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
  * sp >= ep values of a read that stops matching.  If d_locrow is not NULL it
  * receives, per read, the row locate() (seqindex.c:258-277) would pass to
  * unc_sa: sp, or 0xFFFFFFFF where locate() returns -1 (interval empty before
- * the last step) or where sp = n+1 (the reference reads out of bounds there).
+ * the last step), or 0xFFFFFFFE where sp = n+1 (the reference reads out of
+ * bounds there); bwtgpu_locate_rows maps both to "no position".
  * Only the low two bits of a pattern byte are used.
  * Workspace: bwtgpu_search_workspace_bytes(R, m) bytes, 256-byte aligned. */
 size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m);
@@ -107,6 +112,34 @@ size_t bwtgpu_locate_workspace_bytes(void);
 int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R,
                        uint32_t *d_pos, unsigned long long *d_steps,
                        void *d_ws, size_t ws_bytes, void *stream);
+/* Occ(c, idx) for R (symbol, index) pairs: seq_rank (seqindex.c:91-111) when
+ * skip_dollar_row is 0, rank (seqindex.c:221-225) when it is 1.  Indices
+ * beyond n give 0xFFFFFFFF. */
+int bwtgpu_occ_batch(const bwtgpu_index *ix, const uint8_t *d_c, const uint32_t *d_idx,
+                     uint64_t R, int skip_dollar_row, uint32_t *d_out, void *stream);
+/* lf (seqindex.c:214-219) for R rows. */
+int bwtgpu_lf_batch(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R,
+                    uint32_t *d_out, void *stream);
+
+/* ---- host-pointer forms: upload, same kernels, download (synchronous) ---- */
+/* histsort / csuff_arr with the reference's own calling convention
+ * (histsortcomp.c:161, csacak.c:521): host text in, n+1 host rows out. */
+int bwtgpu_sa_build_host(const uint8_t *h_text, uint32_t n, uint32_t *h_sa);
+/* sprintcbwt (histsortcomp.c:220-250) on host arrays. */
+int bwtgpu_bwt_from_sa_host(const uint8_t *h_text, const uint32_t *h_sa, uint32_t n,
+                            uint8_t *h_bwt, uint32_t *endloc);
+/* loc_search over R host reads (seqindex.c:280-309); h_locrow as d_locrow of
+ * bwtgpu_search; with h_pos also locate() (seqindex.c:258-277) per read,
+ * 0xFFFFFFFF standing for its -1.  Each output pointer may be NULL. */
+int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m,
+                       uint64_t stride, uint64_t R, uint32_t *h_sp, uint32_t *h_ep,
+                       uint32_t *h_locrow, uint32_t *h_pos);
+int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R,
+                            uint32_t *h_pos);
+int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *h_idx,
+                    uint64_t R, int skip_dollar_row, uint32_t *h_out);
+int bwtgpu_lf_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R, uint32_t *h_out);
+
 /* ---- seeded synthetic inputs, generated in HBM (bench/test plumbing) ---- */
 /* Bit-identical to the host generators in bwt_amd/synth.py. */
 int bwtgpu_gen_genome(uint8_t *d_text, uint64_t n, uint64_t seed, void *stream);

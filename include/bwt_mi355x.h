@@ -1,0 +1,100 @@
+/*
+ * bwt_mi355x.h -- the drop-in boundary of libbwt_mi355x.so.
+ *
+ * The reference has no plugin or FFI layer: its "operator API" is the set of
+ * non-static C symbols in histsortcomp.h, csacak.h, seqindex.h and fileio.h,
+ * resolved at link time (reference Makefile:32-60).  This header declares
+ * those symbols with the reference's own names, argument order and ownership
+ * rules, so that a caller of histsortcomp.o + csacak.o + seqindex.o + fileio.o
+ * can link libbwt_mi355x.so instead.  Every one of them runs its work on the
+ * MI355X through the device entry points of bwt_gpu.h; none has a CPU path.
+ * If no gfx950 device is usable they print the error to stderr and return the
+ * reference's failure value (NULL / -1 / 0), as the comments say.
+ *
+ * The batch forms at the end have no counterpart in the reference: its
+ * callers loop over reads on the host (fmitest.c:54-65, search_reads.c:102-162)
+ * and that loop is the thing that moves to the GPU.
+ */
+#ifndef BWT_MI355X_H
+#define BWT_MI355X_H
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* seqindex.h:14-22; same field order, types and size (64 bytes on x86-64).
+ * Lengths above 2^31-1 are carried in the same 4 bytes as unsigned values.
+ * rank_index is filled (seq_index layout, blocksize 16) for len < 2^28 and is
+ * NULL above that, where the reference's own rows are wrong (seqindex.c:78). */
+typedef struct _fmi {
+  char *bwt;
+  int *idxs;
+  int **rank_index;
+  unsigned char *lookup;
+  int endloc;
+  int C[5];
+  int len;
+} fm_index;
+
+/* ---- histsortcomp.h:4-20 ---- */
+/* histsortcomp.h:6 / histsortcomp.c:161-180.  malloc'd (len+1) ints, caller frees. */
+int *histsort(const char *str, int len);
+/* histsortcomp.h:20 / histsortcomp.c:220-250.  out holds (len+3)/4 bytes; returns the $ row. */
+unsigned int sprintcbwt(const char *str, unsigned int *idxs, unsigned int len, char *out);
+/* histsortcomp.h:16,18 / histsortcomp.c:195-210 */
+int makecbwt(const char *str, int len, char *out);
+int saca_makecbwt(const char *str, int len, char *out);
+/* histsortcomp.h:14,12,10,8 / histsortcomp.c:183-191,252-287: text forms of the BWT */
+char *makebwt(const char *str, int len);
+void sprintbwt(char *out, const char *str, const int *bwt, int len);
+void putbwt(const char *str, const int *bwt, int len);
+void putsg(const char *str, int idx, int len);
+
+/* ---- csacak.h:3 / csacak.c:521-528: same array as histsort, any input ---- */
+unsigned int *csuff_arr(const char *seq, unsigned int len);
+
+/* ---- seqindex.h:8-67 ---- */
+int **seq_index(char *bwt, int len, int blocksize, const unsigned char *tbl);   /* seqindex.c:23-87 */
+int seq_rank(unsigned char *bwt, int **sidx, int blocksize, int idx, char c,
+             const unsigned char *lookup);                                      /* seqindex.c:91-111 */
+unsigned char *lookup_table(void);                                              /* seqindex.c:115-138 */
+void destroy_fmi(fm_index *fmi);                                                /* seqindex.c:140-157 */
+fm_index *make_fmi(const char *str, int len);                                   /* seqindex.c:161-189 */
+fm_index *make_fmi_sacak(const char *str, int len);                             /* seqindex.c:192-212 */
+int rank(const fm_index *fmi, char c, int idx);                                 /* seqindex.c:221-225 */
+int lf(const fm_index *fmi, int idx);                                           /* seqindex.c:214-219 */
+int reverse_search(const fm_index *fmi, const char *pattern, int len);          /* seqindex.c:228-242 */
+int unc_sa(const fm_index *fmi, int idx);                                       /* seqindex.c:244-255 */
+int locate(const fm_index *fmi, const char *pattern, int len);                  /* seqindex.c:258-277 */
+void loc_search(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep); /* seqindex.c:280-309 */
+void printseq(const char *seq, int startidx, int len);                          /* seqindex.c:354-360 */
+
+/* ---- fileio.h:4-6 / fileio.c:8-65: byte-identical index files ---- */
+void write_index(const fm_index *fmi, FILE *f);
+fm_index *read_index(const char *seq, FILE *f);
+
+/* ---- batch forms (no counterpart in the reference) ---- */
+/* Read r is the len bytes at pats + r*stride, bases 0..3 one per byte.
+ * All return 0, or -1 after printing the device error to stderr. */
+/* loc_search per read: sp[r], ep[r] */
+int fmi_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                     long nreads, int *sp, int *ep);
+/* reverse_search per read: its return value (0, or ep-sp+1) */
+int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                             long nreads, int *result);
+/* locate per read: position, or -1 */
+int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                     long nreads, int *pos);
+/* unc_sa per row */
+int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos);
+
+/* the genome packer of build_index.c:54-87 / search_reads.c:47-80 (tail quirk
+ * included: the last len%4 bases read as A); out holds len/4+1 bytes */
+void fmi_pack_ascii(const char *ascii, long len, char *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -368,6 +368,11 @@ class Reference:
         self.L.loc_search(f.ptr, _p(pat, u8p), len(pat), C.byref(sp), C.byref(ep))
         return sp.value, ep.value
 
+    def locate(self, f, pat):
+        """prints a warning on stdout when the read has several hits"""
+        pat = np.ascontiguousarray(pat, np.uint8)
+        return int(self.L.locate(f.ptr, _p(pat, u8p), len(pat)))
+
     def mms(self, f, pat):
         pat = np.ascontiguousarray(pat, np.uint8)
         sp, ep = C.c_int(), C.c_int()

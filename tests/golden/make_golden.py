@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/golden.json by RUNNING THE UNMODIFIED REFERENCE.
+
+The reference ships no golden outputs (its tests are self-checks and cycle
+counters), so every vector here comes from oracle/_ref/libbwtref.so -- the
+reference's own histsortcomp.c, csacak.c, seqindex.c and fileio.c compiled by
+oracle/Makefile from where they lie -- driven on inputs from the seeded
+generators of the oracle.  Only hashes and tiny vectors are stored; the inputs
+are regenerated from their seeds by the tests.
+
+Run from the repo root, in a container that has /root/reference:
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import load_oracle, load_reference  # noqa: E402
+
+GENOME_SEED = 0x5EED0001
+READS_SEED = 0x5EED0002
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def index_file_sha(ref, fmi):
+    with tempfile.NamedTemporaryFile(suffix=".idx", delete=False) as f:
+        path = f.name
+    try:
+        assert ref.write_index(fmi, path) == 0
+        data = open(path, "rb").read()
+    finally:
+        os.unlink(path)
+    return hashlib.sha256(data).hexdigest(), len(data)
+
+
+def fmi_record(ref, fmi):
+    h, size = index_file_sha(ref, fmi)
+    return {
+        "endloc": fmi.endloc, "C": fmi.C,
+        "bwt": sha(fmi.bwt), "idxs": sha(fmi.idxs), "rank_rows": sha(fmi.rank_rows),
+        "index_file": h, "index_file_bytes": size,
+    }
+
+
+def mms_patterns(orc, text, n, count, m, seed):
+    """reads with some N (code 5) positions, incl. trailing Ns"""
+    reads, _ = orc.gen_reads(text, n, count, m, seed)
+    rng = np.random.default_rng(seed)
+    for r in range(count):
+        k = rng.integers(0, 4)
+        for _ in range(k):
+            reads[r, rng.integers(0, m)] = 5
+        if r % 7 == 0:
+            reads[r, m - 1 - rng.integers(0, 3):] = 5
+        if (reads[r] == 5).all():
+            reads[r, 0] = 1
+    return reads
+
+
+def main():
+    orc = load_oracle()
+    ref = load_reference()
+    if ref is None:
+        raise SystemExit("oracle/_ref/libbwtref.so is missing: run `make -C oracle` where /root/reference exists")
+    G = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref/libbwtref.so (unmodified reference)",
+         "genome_seed": GENOME_SEED, "reads_seed": READS_SEED}
+
+    # 1. the 40-base text of the survey, in full
+    t = np.array([0x1B, 0xE4, 0x00, 0xFF, 0x6C, 0x1B, 0xE4, 0x93, 0x27, 0x4E, 0x00], np.uint8)
+    sa = ref.histsort(t, 40)
+    assert (sa == ref.csuff_arr(t, 40)).all()
+    f = ref.make_fmi(t, 40)
+    G["tiny40"] = {
+        "text_hex": t.tobytes().hex(), "n": 40, "sa": sa.tolist(), "endloc": f.endloc, "C": f.C,
+        "bwt_hex": f.bwt.tobytes().hex(), "idxs": f.idxs.tolist(), "rank_rows": f.rank_rows.tolist(),
+        "loc_search_ACG": list(ref.loc_search(f, [0, 1, 2])), "reverse_search_ACG": ref.reverse_search(f, [0, 1, 2]),
+        "unc_sa": [ref.unc_sa(f, i) for i in range(41)], "lf": [ref.lf(f, i) for i in range(41)],
+        "rank": [[ref.rank(f, c, i) for i in range(42)] for c in range(4)],
+    }
+    G["lookup_table"] = sha(ref.lookup_table())
+
+    # 2. random genomes
+    G["random"] = []
+    for n, R, m in [(13, 0, 0), (777, 2000, 12), (4096, 2000, 20), (100003, 5000, 20), (1000000, 10000, 20),
+                    (1000000, 4000, 50)]:
+        text = orc.gen_genome(n, GENOME_SEED)
+        sa = ref.histsort(text, n)
+        assert (sa == ref.csuff_arr(text, n)).all()
+        f = ref.make_fmi(text, n)
+        rec = {"n": n, "sa": sha(sa), **fmi_record(ref, f)}
+        k = min(n + 1, 5000)
+        rows = np.arange(k, dtype=np.uint32) * ((n + 1) // k)
+        rec["probe_rows_step"] = (n + 1) // k
+        rec["probe_rows"] = k
+        rec["unc_sa"] = sha(ref.locate_rows(f, rows))
+        rec["lf"] = sha(np.array([ref.lf(f, int(r)) for r in rows], np.uint32))
+        if R:
+            reads, offs = orc.gen_reads(text, n, R, m, READS_SEED)
+            sp, ep = ref.search_batch(f, reads, m, m, R)
+            rec.update({"R": R, "m": m, "reads": sha(reads), "sp": sha(sp), "ep": sha(ep)})
+            rec["reverse_search"] = sha(np.array([ref.reverse_search(f, reads[r]) for r in range(R)], np.int32))
+            # locate() prints a warning per multi-hit read; only unique or empty reads are probed
+            loc = []
+            for r in range(R):
+                if ep[r] - sp[r] == 1:
+                    loc.append(ref.locate(f, reads[r]))
+                else:
+                    loc.append(-2)
+            rec["locate_unique"] = sha(np.array(loc, np.int32))
+            pats = mms_patterns(orc, text, n, 300, max(m, 24), 17)
+            rec["mms_m"] = max(m, 24)
+            rec["mms"] = [list(ref.mms(f, pats[r])) for r in range(300)]
+        G["random"].append(rec)
+
+    # 3. repeats: csuff_arr is the reference's own answer here (histsort
+    # overflows its stack beyond a few 10^5 bases of tandem repeat)
+    G["tandem"] = []
+    for n, period, mut in [(20000, 7, 0), (200000, 7, 0), (200000, 1000, 0), (500000, 1000, 997), (300001, 1, 0)]:
+        text = orc.gen_tandem(n, period, 11, mut, 3)
+        sa = ref.csuff_arr(text, n)
+        if n <= 20000:
+            assert (sa == ref.histsort(text, n)).all()
+        f = ref.make_fmi(text, n, sacak=True)
+        G["tandem"].append({"n": n, "period": period, "mut_every": mut, "sa": sha(sa), **fmi_record(ref, f)})
+
+    # 4. the four-thread path of histsort (len >= 10^7, histsortcomp.c:170-175)
+    n = 12000000
+    text = orc.gen_genome(n, GENOME_SEED)
+    sa = ref.histsort(text, n)
+    f = ref.make_fmi(text, n)
+    G["threaded"] = {"n": n, "sa": sha(sa), **fmi_record(ref, f)}
+
+    # 5. build_index's packer: the reference binary's behaviour on ACGTTTT is
+    # recorded in the survey (len 7, C 1 5 6 7 8, endloc 4, idxs 7, bwt 03 18);
+    # here the same text packed as build_index.c:54-87 does it, then indexed
+    packed = orc.pack_ascii(b"ACGTTTT")
+    f = ref.make_fmi(packed, 7, sacak=True)
+    G["packer_ACGTTTT"] = {"packed_hex": packed.tobytes().hex(), "C": f.C, "endloc": f.endloc,
+                           "idxs": f.idxs.tolist(), "bwt_hex": f.bwt.tobytes().hex()}
+    rng = np.random.default_rng(5)
+    ascii_text = bytes(rng.choice(list(b"ACGTacgtN\n"), 1003, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).tolist())
+    packed = orc.pack_ascii(ascii_text)
+    f = ref.make_fmi(packed, len(ascii_text), sacak=True)
+    G["packer_1003"] = {"ascii": ascii_text.decode("latin-1"), "packed": sha(packed),
+                        **fmi_record(ref, f)}
+
+    out = os.path.join(ROOT, "tests", "golden", "golden.json")
+    with open(out, "w") as fp:
+        json.dump(G, fp, indent=1, sort_keys=True)
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()
