@@ -170,30 +170,34 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   sizes[t] = c;
   starts[t] = start;
   __syncthreads();
-  if (t != 0) return;
-  uint32_t run_start = 0, run_size = 0;
-  auto flush = [&]() {
-    if (!run_size) return;
-    const uint32_t k = atomicAdd(&ctr->nleaves, 1u);
-    if (k < leaf_cap) leaves[k] = Leaf{run_start, run_size, depth, dst_id};
-    else ctr->overflow = 1;
-    run_size = 0;
-  };
-  for (int d = 0; d < 256; ++d) {
-    const uint32_t sz = sizes[d];
-    if (!sz) continue;
-    if (sz > kLeafMax) {
-      flush();
-      const uint32_t k = atomicAdd(&ctr->nnext, 1u);
-      if (k < next_cap) next_segs[k] = Seg{starts[d], sz};
-      else ctr->overflow = 1;
-    } else {
-      if (run_size + sz > kLeafMax) flush();
-      if (!run_size) run_start = starts[d];
-      run_size += sz;
+  // greedy merge by one thread into LDS lists, then one reservation per list
+  // and a parallel copy-out (a global atomic per record would serialise)
+  __shared__ uint32_t lstart[256], lsize[256], sidx[256];
+  __shared__ uint32_t nl, ns, lbase, sbase;
+  if (t == 0) {
+    uint32_t run_start = 0, run_size = 0, l = 0, g = 0;
+    for (int d = 0; d < 256; ++d) {
+      const uint32_t sz = sizes[d];
+      if (!sz) continue;
+      if (sz > kLeafMax) {
+        if (run_size) { lstart[l] = run_start; lsize[l] = run_size; ++l; run_size = 0; }
+        sidx[g++] = (uint32_t)d;
+      } else {
+        if (run_size + sz > kLeafMax) { lstart[l] = run_start; lsize[l] = run_size; ++l; run_size = 0; }
+        if (!run_size) run_start = starts[d];
+        run_size += sz;
+      }
     }
+    if (run_size) { lstart[l] = run_start; lsize[l] = run_size; ++l; }
+    nl = l;
+    ns = g;
+    lbase = l ? atomicAdd(&ctr->nleaves, l) : 0u;
+    sbase = g ? atomicAdd(&ctr->nnext, g) : 0u;
+    if (lbase + l > leaf_cap || sbase + g > next_cap) ctr->overflow = 1;
   }
-  flush();
+  __syncthreads();
+  if (t < nl && lbase + t < leaf_cap) leaves[lbase + t] = Leaf{lstart[t], lsize[t], depth, dst_id};
+  if (t < ns && sbase + t < next_cap) next_segs[sbase + t] = Seg{starts[sidx[t]], sizes[sidx[t]]};
 }
 
 __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
@@ -264,16 +268,121 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
 
 // ---- leaves ---------------------------------------------------------------
 
+constexpr uint32_t kDeepRun = 8;     // tie runs up to this long are settled by direct comparison
+constexpr uint32_t kDeepWords = 32;  // ... over at most this many further 16-base words
+
+// LDS slot of element i: one slot of padding per 32 keeps 8-byte accesses at a
+// stride of 16 elements (the blocked layout) free of bank conflicts
+__device__ __forceinline__ uint32_t pad(uint32_t i) { return i + (i >> 5); }
+
+// Element m of thread t when each thread holds the 2^LOGE elements whose index
+// differs in bits [s, s+LOGE): s = 0 is the blocked layout.
+template <int LOGE>
+__device__ __forceinline__ uint32_t lay(uint32_t s, uint32_t t, uint32_t m) {
+  return ((t >> s) << (s + LOGE)) | (m << s) | (t & ((1u << s) - 1u));
+}
+
+__device__ __forceinline__ void cex(uint64_t &a, uint64_t &b, bool asc) {
+  const bool sw = (a > b) == asc;
+  const uint64_t x = sw ? b : a, y = sw ? a : b;
+  a = x;
+  b = y;
+}
+
+// Bitonic sort of 256 << LOGE keys, 2^LOGE per thread, compare-exchanges done in
+// registers: a stage whose stride bit lies outside the bits a thread holds
+// costs one trip through LDS that re-deals the elements, and each trip then
+// serves up to LOGE stages.  Ends in the blocked layout.
+template <int LOGE>
+__device__ __forceinline__ void leaf_bitonic(uint64_t (&r)[1 << LOGE], uint64_t *lds, uint32_t t) {
+  constexpr int E = 1 << LOGE;
+  constexpr int LOGP = LOGE + 8;
+#pragma unroll
+  for (int lk = 1; lk <= LOGE; ++lk) {
+#pragma unroll
+    for (int lb = lk - 1; lb >= 0; --lb) {
+#pragma unroll
+      for (int m = 0; m < E; ++m)
+        if (!(m & (1 << lb))) cex(r[m], r[m | (1 << lb)], (((t * E + m) >> lk) & 1u) == 0);
+    }
+  }
+  uint32_t cur = 0;
+  for (int lk = LOGE + 1; lk <= LOGP; ++lk) {
+    int jb = lk - 1;
+    while (jb >= 0) {
+      const uint32_t s = jb >= LOGE - 1 ? (uint32_t)(jb - (LOGE - 1)) : 0u;
+      if (s != cur) {
+#pragma unroll
+        for (int m = 0; m < E; ++m) lds[pad(lay<LOGE>(cur, t, m))] = r[m];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < E; ++m) r[m] = lds[pad(lay<LOGE>(s, t, m))];
+        __syncthreads();
+        cur = s;
+      }
+#pragma unroll
+      for (int lb = LOGE - 1; lb >= 0; --lb) {
+        if ((int)s + lb > jb) continue;
+#pragma unroll
+        for (int m = 0; m < E; ++m)
+          if (!(m & (1 << lb)))
+            cex(r[m], r[m | (1 << lb)], ((lay<LOGE>(s, t, m) >> lk) & 1u) == 0);
+      }
+      jb = (int)s - 1;
+    }
+  }
+}
+
+template <int LOGE>
+__device__ __forceinline__ void leaf_load_sort(const uint32_t *__restrict__ tb,
+                                               const uint32_t *__restrict__ src, uint32_t start,
+                                               uint32_t size, uint32_t depth, uint64_t *lds,
+                                               uint32_t t) {
+  constexpr int E = 1 << LOGE;
+  uint64_t r[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t j = t * E + m;
+    uint64_t v = ~0ull;
+    if (j < size) {
+      const uint32_t id = src ? src[start + j] : start + j;
+      v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
+    }
+    r[m] = v;
+  }
+  leaf_bitonic<LOGE>(r, lds, t);
+#pragma unroll
+  for (int m = 0; m < E; ++m) lds[pad(t * E + m)] = r[m];
+}
+
+// Order of two suffixes that agree on their first `off` bases: -1 if a comes
+// first, +1 if b does, 0 if still undecided after kDeepWords words.  Past the
+// end of the text a suffix reads as A's; two suffixes equal all the way are
+// ordered shorter first.
+__device__ __forceinline__ int deep_cmp(const uint32_t *__restrict__ tb, uint32_t n, uint32_t a,
+                                        uint32_t b, uint32_t off) {
+  for (uint32_t w = 0; w < kDeepWords; ++w) {
+    const uint64_t pa = (uint64_t)a + off + 16ull * w, pb = (uint64_t)b + off + 16ull * w;
+    const bool ea = pa >= n, eb = pb >= n;
+    if (ea && eb) return a > b ? -1 : 1;
+    const uint32_t ka = ea ? 0u : key32(tb, pa), kb = eb ? 0u : key32(tb, pb);
+    if (ka != kb) return ka < kb ? -1 : 1;
+  }
+  return 0;
+}
+
 // One workgroup sorts one leaf in LDS by (next 16 bases ascending, start
-// descending), writes the rows of the suffix array, and records for every row
-// the first row of its tie group (its own row when resolved).
+// descending), settles short runs of equal keys by comparing the suffixes
+// further, writes the rows of the suffix array, and records for every row the
+// first row of its tie group (its own row when resolved).
 __global__ void __launch_bounds__(256)
 k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             const uint32_t *__restrict__ bufB, const Leaf *__restrict__ leaves, uint32_t n,
             uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
             Counters *__restrict__ ctr) {
-  __shared__ uint64_t keys[kLeafMax];
-  __shared__ uint32_t wred[4];
+  __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
+  __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
+  __shared__ uint32_t wred[4], wmax[4];
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
@@ -285,35 +394,74 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     }
     return;
   }
+  if (t < kLeafMax / 32) settled[t] = 0;
   uint32_t P = 2;
   while (P < size) P <<= 1;
-  for (uint32_t j = t; j < P; j += 256) {
-    uint64_t v = ~0ull;
-    if (j < size) {
-      const uint32_t id = src ? src[start + j] : start + j;
-      v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
+  if (P == 4096) {
+    leaf_load_sort<4>(tb, src, start, size, depth, keys, t);
+  } else if (P == 2048) {
+    leaf_load_sort<3>(tb, src, start, size, depth, keys, t);
+  } else if (P == 1024) {
+    leaf_load_sort<2>(tb, src, start, size, depth, keys, t);
+  } else if (P == 512) {
+    leaf_load_sort<1>(tb, src, start, size, depth, keys, t);
+  } else {
+    for (uint32_t j = t; j < P; j += 256) {
+      uint64_t v = ~0ull;
+      if (j < size) {
+        const uint32_t id = src ? src[start + j] : start + j;
+        v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
+      }
+      keys[pad(j)] = v;
     }
-    keys[j] = v;
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t q = t; q < (P >> 1); q += 256) {
+          const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+          const uint32_t x = i | j;
+          const uint64_t a = keys[pad(i)], b = keys[pad(x)];
+          if ((a > b) == ((i & k) == 0)) {
+            keys[pad(i)] = b;
+            keys[pad(x)] = a;
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
   __syncthreads();
-  for (uint32_t k = 2; k <= P; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t q = t; q < (P >> 1); q += 256) {
-        const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-        const uint32_t x = i | j;
-        const uint64_t a = keys[i], b = keys[x];
-        const bool asc = (i & k) == 0;
-        if ((a > b) == asc) {
-          keys[i] = b;
-          keys[x] = a;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // tie flags and group heads, blocked: thread t owns rows [t*per, t*per+per)
+  // blocked from here on: thread t owns rows [t*per, t*per+per)
   const uint32_t per = (P + 255) / 256;  // 1..16
   const uint32_t j0 = t * per;
+  // short runs of equal keys: the thread that owns the first row of a run
+  // orders the whole run by comparing the suffixes beyond the key
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t j = j0 + k;
+    if (j + 1 >= size) break;
+    const uint32_t key = (uint32_t)(keys[pad(j)] >> 32);
+    if ((uint32_t)(keys[pad(j + 1)] >> 32) != key) continue;
+    if (j > 0 && (uint32_t)(keys[pad(j - 1)] >> 32) == key) continue;
+    uint32_t e = j + 2;
+    while (e < size && e - j <= kDeepRun && (uint32_t)(keys[pad(e)] >> 32) == key) ++e;
+    if (e - j > kDeepRun) continue;
+    bool ok = true;
+    for (uint32_t a = j + 1; a < e && ok; ++a) {
+      const uint64_t v = keys[pad(a)];
+      uint32_t b = a;
+      while (b > j) {
+        const int c = deep_cmp(tb, n, ~(uint32_t)v, ~(uint32_t)keys[pad(b - 1)], depth + kLeafKeyBases);
+        if (c == 0) ok = false;
+        if (c >= 0) break;
+        keys[pad(b)] = keys[pad(b - 1)];
+        --b;
+      }
+      keys[pad(b)] = v;
+    }
+    if (ok)
+      for (uint32_t a = j + 1; a < e; ++a) atomicOr(&settled[a >> 5], 1u << (a & 31u));
+  }
+  __syncthreads();
   uint32_t hv[16];
   uint32_t local_max = 0, tied_rows = 0;
 #pragma unroll
@@ -322,20 +470,21 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     const uint32_t j = j0 + k;
     if (k < per && j < size) {
       bool tie = false, tie_next = false;
-      const uint64_t cur = keys[j];
+      const uint64_t cur = keys[pad(j)];
       if (j > 0) {
-        const uint64_t prv = keys[j - 1];
+        const uint64_t prv = keys[pad(j - 1)];
         const uint32_t pid = ~(uint32_t)prv;
         // the previous suffix is final here if its key window ran past the
         // end of the text: a shorter suffix precedes every longer one it ties
         tie = (uint32_t)(prv >> 32) == (uint32_t)(cur >> 32) &&
-              (uint64_t)pid + depth + kLeafKeyBases < n;
+              (uint64_t)pid + depth + kLeafKeyBases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
       }
       if (j + 1 < size) {
-        const uint64_t nxt = keys[j + 1];
+        const uint64_t nxt = keys[pad(j + 1)];
         const uint32_t cid = ~(uint32_t)cur;
         tie_next = (uint32_t)(nxt >> 32) == (uint32_t)(cur >> 32) &&
-                   (uint64_t)cid + depth + kLeafKeyBases < n;
+                   (uint64_t)cid + depth + kLeafKeyBases < n &&
+                   !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
       }
       hv[k] = tie ? 0u : 1u + start + j;
       tied_rows += (tie || tie_next) ? 1u : 0u;
@@ -351,7 +500,6 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   }
   uint32_t tr = tied_rows;
   for (int off = 32; off; off >>= 1) tr += __shfl_down(tr, off, 64);
-  __shared__ uint32_t wmax[4];
   if (lane == 63) wmax[wave] = v;
   if (lane == 0) wred[wave] = tr;
   __syncthreads();
@@ -374,18 +522,18 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     const uint32_t j = j0 + k;
     if (k < per && j < size) {
       run = hv[k] > run ? hv[k] : run;
-      outv[k] = ((uint64_t)run << 32) | (uint32_t)~(uint32_t)keys[j];
+      outv[k] = ((uint64_t)run << 32) | (uint32_t)~(uint32_t)keys[pad(j)];
     }
   }
   __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < 16; ++k) {
     const uint32_t j = j0 + k;
-    if (k < per && j < size) keys[j] = outv[k];
+    if (k < per && j < size) keys[pad(j)] = outv[k];
   }
   __syncthreads();
   for (uint32_t j = t; j < size; j += 256) {
-    const uint64_t o = keys[j];
+    const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
     ghead[1 + start + j] = (uint32_t)(o >> 32);
   }
