@@ -34,6 +34,7 @@ SIGNATURES = {
     "bwtgpu_bwt_from_sa": (C.c_int, [vp, vp, u32, vp, vp, vp]),
     "bwtgpu_index_build": (vp, [vp, u32, vp]),
     "bwtgpu_index_build_dev": (vp, [vp, u32, vp]),
+    "bwtgpu_release_cache": (C.c_int, []),
     "bwtgpu_index_from_parts": (vp, [vp, u32, u32, vp, vp]),
     "bwtgpu_index_free": (None, [vp]),
     "bwtgpu_index_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),

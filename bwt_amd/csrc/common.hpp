@@ -129,7 +129,14 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
 int index_alloc(bwtgpu_index **out, uint32_t n);
 
 // sa_build.hip
+// By-products of a build whose rows all came out of the leaf sort (no prefix
+// doubling): the BWT symbol of every row of SA+1, and the $ row.  Both live in
+// the workspace; null when not available.
+struct SaExtras {
+  const uint8_t *bw = nullptr;
+  const uint32_t *endloc = nullptr;
+};
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
-                  size_t ws_bytes, hipStream_t s);
+                  size_t ws_bytes, hipStream_t s, SaExtras *extras);
 
 }  // namespace bwtgpu

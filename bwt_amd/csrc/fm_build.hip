@@ -44,6 +44,31 @@ k_emit_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa,
   }
 }
 
+// Same, when the suffix-array build left the BWT symbol of every row behind
+// (bw[r-1] for row r >= 1): a streaming pass, no gather.  Row 0 is the $ suffix,
+// preceded by the last base of the text.
+__global__ void __launch_bounds__(256)
+k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__ bw, uint32_t n,
+                   const uint32_t *__restrict__ d_endloc, IndexBlock *__restrict__ blocks,
+                   uint64_t nblocks) {
+  const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (b >= nblocks) return;  // wave-uniform
+  const uint32_t endloc = *d_endloc;
+  const uint64_t p = b * 64 + lane;
+  uint32_t base = 0;
+  if (p < n) {
+    const uint64_t row = p + (p >= endloc ? 1 : 0);
+    base = row ? bw[row - 1] : text_base(text, (uint64_t)n - 1);
+  }
+  const uint64_t lo = __ballot(base & 1u);
+  const uint64_t hi = __ballot(base & 2u);
+  if (lane == 0) {
+    blocks[b].lo = lo;
+    blocks[b].hi = hi;
+  }
+}
+
 __global__ void k_sample_sa(const uint32_t *__restrict__ sa, uint64_t nsamples,
                             uint32_t *__restrict__ idxs) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,36 +94,78 @@ __global__ void k_emit_bwt_bytes(const uint8_t *__restrict__ text, const uint32_
   bwt[q] = (uint8_t)acc;
 }
 
+// The suffix array and the build workspace are transient and large (about
+// 21 bytes per base); allocating and freeing them costs more than a millisecond
+// per build, so the calling thread keeps the largest pair it has used on its
+// device until bwtgpu_release_cache().
+struct BuildCache {
+  int device = -1;
+  void *sa = nullptr, *ws = nullptr, *small = nullptr;
+  size_t sa_bytes = 0, ws_bytes = 0;
+  void release() {
+    if (sa) (void)hipFree(sa);
+    if (ws) (void)hipFree(ws);
+    if (small) (void)hipFree(small);
+    sa = ws = small = nullptr;
+    sa_bytes = ws_bytes = 0;
+    device = -1;
+  }
+};
+static thread_local BuildCache g_cache;
+
+static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
+  int dev = 0;
+  BWT_HIP(hipGetDevice(&dev));
+  if (g_cache.device != dev) g_cache.release();
+  g_cache.device = dev;
+  if (!g_cache.small) BWT_HIP(hipMalloc(&g_cache.small, 4096));
+  if (g_cache.sa_bytes < sa_bytes) {
+    if (g_cache.sa) (void)hipFree(g_cache.sa);
+    g_cache.sa = nullptr;
+    g_cache.sa_bytes = 0;
+    BWT_HIP(hipMalloc(&g_cache.sa, sa_bytes));
+    g_cache.sa_bytes = sa_bytes;
+  }
+  if (g_cache.ws_bytes < ws_bytes) {
+    if (g_cache.ws) (void)hipFree(g_cache.ws);
+    g_cache.ws = nullptr;
+    g_cache.ws_bytes = 0;
+    BWT_HIP(hipMalloc(&g_cache.ws, ws_bytes));
+    g_cache.ws_bytes = ws_bytes;
+  }
+  return kOk;
+}
+
 static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t s,
                                   bwtgpu_index **out) {
   bwtgpu_index *ix = nullptr;
   BWT_TRY(index_alloc(&ix, n));
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
-  uint32_t *d_sa = nullptr;
-  void *d_ws = nullptr;
-  uint32_t *d_endloc = nullptr;
-  int rc = kOk;
-  auto cleanup = [&]() {
-    if (d_sa) (void)hipFree(d_sa);
-    if (d_ws) (void)hipFree(d_ws);
-    if (d_endloc) (void)hipFree(d_endloc);
-  };
-  hipError_t e = hipMalloc(&d_sa, ((size_t)n + 1) * 4);
-  if (e == hipSuccess) e = hipMalloc(&d_ws, ws_bytes);
-  if (e == hipSuccess) e = hipMalloc(&d_endloc, 256);
-  if (e != hipSuccess) {
-    cleanup();
+  int rc = cache_reserve(((size_t)n + 1) * 4, ws_bytes);
+  if (rc != kOk) {
     bwtgpu_index_free(ix);
-    return set_error(kErrHip, "index build buffers for n=%u: %s", n, hipGetErrorString(e));
+    return rc;
   }
-  rc = sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, s);
+  uint32_t *d_sa = reinterpret_cast<uint32_t *>(g_cache.sa);
+  void *d_ws = g_cache.ws;
+  uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
+  auto cleanup = [&]() {};
+  hipError_t e = hipSuccess;
+  SaExtras extras;
+  rc = sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, s, &extras);
   if (rc == kOk) {
     const uint64_t rows = (uint64_t)n + 1;
-    (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
-    BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa,
-               rows, d_endloc);
-    BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0,
-               s, d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
+    if (extras.bw) {
+      (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
+      BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows, dim3((unsigned)div_up(ix->nblocks * 64, 256)),
+                 dim3(256), 0, s, d_text, extras.bw, n, d_endloc, ix->d_blocks, ix->nblocks);
+    } else {
+      (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
+      BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa,
+                 rows, d_endloc);
+      BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0,
+                 s, d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
+    }
     const uint64_t ns = (uint64_t)n / 32 + 1;
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns,
                ix->d_idxs);
@@ -122,6 +189,11 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
 using namespace bwtgpu;
 
 extern "C" {
+
+int bwtgpu_release_cache(void) {
+  g_cache.release();
+  return kOk;
+}
 
 int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, uint8_t *d_bwt,
                        uint32_t *d_endloc, void *stream) {

@@ -31,7 +31,7 @@ constexpr int kPartTile = kPartThreads * kPartItems;  // 4096 suffixes per tile
 constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
 constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
 constexpr uint32_t kMaxDepth = 24;                    // bucket levels stop here; doubling takes over
-constexpr uint32_t kLeafKeyBases = 16;                // bases in a leaf sort key
+constexpr uint32_t kLeafKeyBases = 15;                // bases in a leaf sort key
 constexpr uint32_t kTextPadWords = 8;
 
 enum : uint32_t { kSrcA = 0, kSrcB = 1, kSrcImplicit = 2 };
@@ -51,7 +51,7 @@ struct Counters {
   uint32_t overflow;    // a list ran out of room (reported as an error)
   uint32_t total_tiles;
   uint32_t active;      // doubling: rows still in groups
-  uint32_t pad;
+  uint32_t endloc;      // SA row whose suffix starts at 0 (the $ of the BWT)
 };
 
 // ---- text -------------------------------------------------------------
@@ -80,6 +80,21 @@ __device__ __forceinline__ uint32_t key32(const uint32_t *__restrict__ tb, uint6
   const uint32_t sh = 2u * (uint32_t)(p & 15u);
   const uint64_t both = ((uint64_t)tb[w] << 32) | tb[w + 1];
   return (uint32_t)((both << sh) >> 32);
+}
+
+// base just before position p (p >= 1)
+__device__ __forceinline__ uint32_t base_before(const uint32_t *__restrict__ tb, uint64_t p) {
+  const uint64_t q = p - 1;
+  return (tb[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u;
+}
+
+// What travels with a suffix id from the scatter to the leaf sort: the 15
+// bases after the bucket prefix (the sort key) and, in the low two bits, the
+// base that precedes the suffix (its BWT symbol), both read from the same
+// line of text while the scatter has it in hand.
+__device__ __forceinline__ uint32_t carried_word(const uint32_t *__restrict__ tb, uint32_t id,
+                                                 uint32_t key) {
+  return (key & ~3u) | (id ? base_before(tb, id) : 0u);
 }
 
 // ---- one bucket level ----------------------------------------------------
@@ -212,26 +227,27 @@ __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
 template <bool IMPLICIT>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
-               uint32_t *__restrict__ dst, const Seg *__restrict__ segs,
-               const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
-               const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors) {
+               uint32_t *__restrict__ dst, uint32_t *__restrict__ dstkey,
+               const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+               uint32_t depth, const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors) {
   __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4];
   __shared__ uint32_t ids[kPartTile];
-  __shared__ uint8_t digs[kPartTile];
+  __shared__ uint32_t kv[kPartTile];
   __shared__ TileInfo ti;
   const uint32_t t = threadIdx.x;
   hist[t] = 0;
   fill[t] = 0;
   if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
-  uint32_t id[kPartItems], dg[kPartItems];
+  uint32_t id[kPartItems], key[kPartItems];
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
     const uint32_t j = (uint32_t)i * kPartThreads + t;
     if (j < count) {
       id[i] = IMPLICIT ? row0 + j : src[row0 + j];
-      dg[i] = key32(tb, (uint64_t)id[i] + depth) >> 24;
-      atomicAdd(&hist[dg[i]], 1u);
+      key[i] = key32(tb, (uint64_t)id[i] + depth);
+      atomicAdd(&hist[key[i] >> 24], 1u);
+      key[i] = carried_word(tb, id[i], key[i]);
     }
   }
   __syncthreads();
@@ -254,15 +270,18 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   for (int i = 0; i < kPartItems; ++i) {
     const uint32_t j = (uint32_t)i * kPartThreads + t;
     if (j < count) {
-      const uint32_t p = lstart[dg[i]] + atomicAdd(&fill[dg[i]], 1u);
+      const uint32_t d = key[i] >> 24;
+      const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
-      digs[p] = (uint8_t)dg[i];
+      kv[p] = key[i];
     }
   }
   __syncthreads();
   for (uint32_t j = t; j < count; j += kPartThreads) {
-    const uint32_t d = digs[j];
-    dst[gbase[d] + (j - lstart[d])] = ids[j];
+    const uint32_t k = kv[j], d = k >> 24;
+    const uint32_t pos = gbase[d] + (j - lstart[d]);
+    dst[pos] = ids[j];
+    dstkey[pos] = k;
   }
 }
 
@@ -333,9 +352,26 @@ __device__ __forceinline__ void leaf_bitonic(uint64_t (&r)[1 << LOGE], uint64_t 
   }
 }
 
+// Sort word of a suffix: 30 key bits, then the complement of the start (equal
+// keys: larger start first), then the two bits of its BWT symbol (payload).
+__device__ __forceinline__ uint64_t leaf_word(uint32_t carried, uint32_t id) {
+  return ((uint64_t)(carried >> 2) << 34) | ((uint64_t)(uint32_t)~id << 2) | (carried & 3u);
+}
+__device__ __forceinline__ uint32_t word_key(uint64_t w) { return (uint32_t)(w >> 34); }
+__device__ __forceinline__ uint32_t word_id(uint64_t w) { return ~(uint32_t)(w >> 2); }
+
+__device__ __forceinline__ uint64_t leaf_fetch(const uint32_t *__restrict__ tb,
+                                               const uint32_t *__restrict__ src,
+                                               const uint32_t *__restrict__ srckey, uint32_t row,
+                                               uint32_t depth) {
+  if (src) return leaf_word(srckey[row], src[row]);
+  return leaf_word(carried_word(tb, row, key32(tb, (uint64_t)row + depth)), row);
+}
+
 template <int LOGE>
 __device__ __forceinline__ void leaf_load_sort(const uint32_t *__restrict__ tb,
-                                               const uint32_t *__restrict__ src, uint32_t start,
+                                               const uint32_t *__restrict__ src,
+                                               const uint32_t *__restrict__ srckey, uint32_t start,
                                                uint32_t size, uint32_t depth, uint64_t *lds,
                                                uint32_t t) {
   constexpr int E = 1 << LOGE;
@@ -343,12 +379,7 @@ __device__ __forceinline__ void leaf_load_sort(const uint32_t *__restrict__ tb,
 #pragma unroll
   for (int m = 0; m < E; ++m) {
     const uint32_t j = t * E + m;
-    uint64_t v = ~0ull;
-    if (j < size) {
-      const uint32_t id = src ? src[start + j] : start + j;
-      v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
-    }
-    r[m] = v;
+    r[m] = j < size ? leaf_fetch(tb, src, srckey, start + j, depth) : ~0ull;
   }
   leaf_bitonic<LOGE>(r, lds, t);
 #pragma unroll
@@ -377,8 +408,10 @@ __device__ __forceinline__ int deep_cmp(const uint32_t *__restrict__ tb, uint32_
 // first row of its tie group (its own row when resolved).
 __global__ void __launch_bounds__(256)
 k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
-            const uint32_t *__restrict__ bufB, const Leaf *__restrict__ leaves, uint32_t n,
+            const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+            const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
             uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
+            uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
             Counters *__restrict__ ctr) {
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
@@ -386,11 +419,15 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
+  const uint32_t *srckey = lf.src == kSrcA ? keyA : keyB;
   if (size == 1) {
     if (t == 0) {
-      const uint32_t id = src ? src[start] : start;
+      const uint64_t w = leaf_fetch(tb, src, srckey, start, depth);
+      const uint32_t id = word_id(w);
       sa_rows[start] = id;
       ghead[1 + start] = 1 + start;
+      bw[start] = (uint8_t)(w & 3u);
+      if (id == 0) ctr->endloc = 1 + start;
     }
     return;
   }
@@ -398,22 +435,16 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   uint32_t P = 2;
   while (P < size) P <<= 1;
   if (P == 4096) {
-    leaf_load_sort<4>(tb, src, start, size, depth, keys, t);
+    leaf_load_sort<4>(tb, src, srckey, start, size, depth, keys, t);
   } else if (P == 2048) {
-    leaf_load_sort<3>(tb, src, start, size, depth, keys, t);
+    leaf_load_sort<3>(tb, src, srckey, start, size, depth, keys, t);
   } else if (P == 1024) {
-    leaf_load_sort<2>(tb, src, start, size, depth, keys, t);
+    leaf_load_sort<2>(tb, src, srckey, start, size, depth, keys, t);
   } else if (P == 512) {
-    leaf_load_sort<1>(tb, src, start, size, depth, keys, t);
+    leaf_load_sort<1>(tb, src, srckey, start, size, depth, keys, t);
   } else {
-    for (uint32_t j = t; j < P; j += 256) {
-      uint64_t v = ~0ull;
-      if (j < size) {
-        const uint32_t id = src ? src[start + j] : start + j;
-        v = ((uint64_t)key32(tb, (uint64_t)id + depth) << 32) | (uint32_t)~id;
-      }
-      keys[pad(j)] = v;
-    }
+    for (uint32_t j = t; j < P; j += 256)
+      keys[pad(j)] = j < size ? leaf_fetch(tb, src, srckey, start + j, depth) : ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= P; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -439,18 +470,18 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t j = j0 + k;
     if (j + 1 >= size) break;
-    const uint32_t key = (uint32_t)(keys[pad(j)] >> 32);
-    if ((uint32_t)(keys[pad(j + 1)] >> 32) != key) continue;
-    if (j > 0 && (uint32_t)(keys[pad(j - 1)] >> 32) == key) continue;
+    const uint32_t key = word_key(keys[pad(j)]);
+    if (word_key(keys[pad(j + 1)]) != key) continue;
+    if (j > 0 && word_key(keys[pad(j - 1)]) == key) continue;
     uint32_t e = j + 2;
-    while (e < size && e - j <= kDeepRun && (uint32_t)(keys[pad(e)] >> 32) == key) ++e;
+    while (e < size && e - j <= kDeepRun && word_key(keys[pad(e)]) == key) ++e;
     if (e - j > kDeepRun) continue;
     bool ok = true;
     for (uint32_t a = j + 1; a < e && ok; ++a) {
       const uint64_t v = keys[pad(a)];
       uint32_t b = a;
       while (b > j) {
-        const int c = deep_cmp(tb, n, ~(uint32_t)v, ~(uint32_t)keys[pad(b - 1)], depth + kLeafKeyBases);
+        const int c = deep_cmp(tb, n, word_id(v), word_id(keys[pad(b - 1)]), depth + kLeafKeyBases);
         if (c == 0) ok = false;
         if (c >= 0) break;
         keys[pad(b)] = keys[pad(b - 1)];
@@ -473,16 +504,16 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
       const uint64_t cur = keys[pad(j)];
       if (j > 0) {
         const uint64_t prv = keys[pad(j - 1)];
-        const uint32_t pid = ~(uint32_t)prv;
+        const uint32_t pid = word_id(prv);
         // the previous suffix is final here if its key window ran past the
         // end of the text: a shorter suffix precedes every longer one it ties
-        tie = (uint32_t)(prv >> 32) == (uint32_t)(cur >> 32) &&
+        tie = word_key(prv) == word_key(cur) &&
               (uint64_t)pid + depth + kLeafKeyBases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
       }
       if (j + 1 < size) {
         const uint64_t nxt = keys[pad(j + 1)];
-        const uint32_t cid = ~(uint32_t)cur;
-        tie_next = (uint32_t)(nxt >> 32) == (uint32_t)(cur >> 32) &&
+        const uint32_t cid = word_id(cur);
+        tie_next = word_key(nxt) == word_key(cur) &&
                    (uint64_t)cid + depth + kLeafKeyBases < n &&
                    !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
       }
@@ -521,8 +552,12 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   for (uint32_t k = 0; k < 16; ++k) {
     const uint32_t j = j0 + k;
     if (k < per && j < size) {
+      const uint64_t w = keys[pad(j)];
+      const uint32_t id = word_id(w);
       run = hv[k] > run ? hv[k] : run;
-      outv[k] = ((uint64_t)run << 32) | (uint32_t)~(uint32_t)keys[pad(j)];
+      outv[k] = ((uint64_t)run << 32) | id;
+      bw[start + j] = (uint8_t)(w & 3u);
+      if (id == 0) ctr->endloc = 1 + start + j;
     }
   }
   __syncthreads();
@@ -726,7 +761,7 @@ static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0,
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, ghead, segs0, segs1, counts, tile_first, leaves, ctr, scanws, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, tile_first, leaves, ctr, scanws, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -744,6 +779,9 @@ static Layout layout_for(uint32_t n) {
   };
   L.tb = take(L.nwords * 4);
   L.bufB = take(((size_t)n + 1) * 4);
+  L.keyA = take(((size_t)n + 1) * 4);
+  L.keyB = take(((size_t)n + 1) * 4);
+  L.bw = take((size_t)n + 1);
   L.ghead = take(((size_t)n + 1) * 4);
   L.segs0 = take((size_t)L.seg_cap * sizeof(Seg));
   L.segs1 = take((size_t)L.seg_cap * sizeof(Seg));
@@ -757,7 +795,8 @@ static Layout layout_for(uint32_t n) {
 }
 
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,
-                  hipStream_t s) {
+                  hipStream_t s, SaExtras *extras) {
+  if (extras) *extras = SaExtras{};
   if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
   if (n == 0 || n > 0xFFFFFFF0u) return set_error(kErrArg, "text length %u out of range", n);
   if ((uintptr_t)d_ws & 255u) return set_error(kErrArg, "workspace must be 256-byte aligned");
@@ -767,6 +806,9 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   uint32_t *tb = reinterpret_cast<uint32_t *>(ws + L.tb);
   uint32_t *bufA = d_sa + 1;
   uint32_t *bufB = reinterpret_cast<uint32_t *>(ws + L.bufB);
+  uint32_t *keyA = reinterpret_cast<uint32_t *>(ws + L.keyA);
+  uint32_t *keyB = reinterpret_cast<uint32_t *>(ws + L.keyB);
+  uint8_t *bw = ws + L.bw;
   uint32_t *ghead = reinterpret_cast<uint32_t *>(ws + L.ghead);
   Seg *segs[2] = {reinterpret_cast<Seg *>(ws + L.segs0), reinterpret_cast<Seg *>(ws + L.segs1)};
   uint32_t *counts = reinterpret_cast<uint32_t *>(ws + L.counts);
@@ -804,6 +846,7 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
     const uint32_t dst_id = src_id == kSrcA ? kSrcB : kSrcA;
     const uint32_t *src = src_id == kSrcA ? bufA : src_id == kSrcB ? bufB : nullptr;
     uint32_t *dst = dst_id == kSrcA ? bufA : bufB;
+    uint32_t *dstkey = dst_id == kSrcA ? keyA : keyB;
     // tiles of this level's segments
     BWT_LAUNCH("sa_seg_tiles", k_seg_tile_counts, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s,
                segs[cur], nsegs, tile_first);
@@ -823,10 +866,10 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
                dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, ctr);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, dst, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 src, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     } else {
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, dst, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 src, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     }
     BWT_CHECK_LAUNCH();
     BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
@@ -843,8 +886,8 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   g_stats.v[1] = nleaves_host;
   g_stats.v[4] = depth;
   if (nleaves_host)
-    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(256), 0, s, tb, bufA, bufB, leaves, n,
-               bufA, ghead, ctr);
+    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(256), 0, s, tb, bufA, bufB, keyA, keyB,
+               leaves, n, bufA, ghead, bw, ctr);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
     BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
@@ -854,6 +897,11 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
   BWT_HIP(hipStreamSynchronize(s));
   g_stats.v[2] = h_ctr.unresolved;
+  if (extras && !h_ctr.unresolved && !nsegs) {
+    // every row came out of a leaf sort: its BWT symbol and the $ row are known
+    extras->bw = bw;
+    extras->endloc = &ctr->endloc;
+  }
   if (h_ctr.unresolved) {
     // bufB is free from here on: reuse it for the active-row flags
     BWT_TRY(sa_doubling(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
@@ -871,7 +919,7 @@ size_t bwtgpu_sa_workspace_bytes(uint32_t n) { return layout_for(n ? n : 1).end;
 
 int bwtgpu_sa_build(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,
                     void *stream) {
-  return sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, (hipStream_t)stream);
+  return sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, (hipStream_t)stream, nullptr);
 }
 
 int bwtgpu_sa_last_stats(uint64_t stats[8]) {

@@ -66,8 +66,11 @@ int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n,
  * 32nd SA row (seqindex.c:173-176), BWT, rank blocks, C[].  h_text is the
  * packed text on the host (n/4+1 bytes).  The SA never leaves the device. */
 bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream);
-/* Same from a packed text already in HBM. */
+/* Same from a packed text already in HBM.  Both keep the suffix array and
+ * workspace buffers (about 21 bytes per base) cached on the calling thread for
+ * the next build; bwtgpu_release_cache() frees them. */
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream);
+int bwtgpu_release_cache(void);
 /* Replaces the rebuild half of read_index (fileio.c:44-63): takes the stored
  * parts of an index (host pointers) and rebuilds the rank blocks on device.
  * h_idxs may be NULL (no locate on such an index). */
