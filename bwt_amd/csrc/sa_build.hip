@@ -114,10 +114,10 @@ struct TileInfo {
   uint32_t seg, row0, count;
 };
 
-__device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *tile_first,
-                                            uint32_t nsegs, const Counters *ctr, TileInfo *sh) {
+__device__ __forceinline__ bool locate_tile_at(uint32_t tile, const Seg *segs,
+                                               const uint32_t *tile_first, uint32_t nsegs,
+                                               const Counters *ctr, TileInfo *sh) {
   if (threadIdx.x == 0) {
-    const uint32_t tile = blockIdx.x;
     if (tile >= ctr->total_tiles) {
       sh->count = 0;
     } else {
@@ -134,28 +134,63 @@ __device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *til
   return sh->count != 0;
 }
 
-// LDS-privatised histogram of the next four bases of every suffix in a tile.
-template <bool IMPLICIT>
+__device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *tile_first,
+                                            uint32_t nsegs, const Counters *ctr, TileInfo *sh) {
+  return locate_tile_at(blockIdx.x, segs, tile_first, nsegs, ctr, sh);
+}
+
+constexpr uint32_t kHistTilesPerGroup = 8;
+
+// LDS-privatised histogram of the next four bases of every suffix in a run of
+// tiles; counts go to the segment's counters when the run leaves the segment.
+// MODE 0: ids are implicit (level 0: the tile is a range of text positions);
+// MODE 1: ids from src, bases from the text;
+// MODE 2: the bases are bits 23..16 of the word the previous level's scatter
+//         stored next to the id (its key started four bases earlier): no gather.
+template <int MODE>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
-            const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
-            uint32_t depth, const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
+            const uint32_t *__restrict__ srckey, const Seg *__restrict__ segs,
+            const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
+            const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
   __shared__ uint32_t hist[256];
   __shared__ TileInfo ti;
   hist[threadIdx.x] = 0;
-  if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
-  const uint32_t row0 = ti.row0, count = ti.count;
-#pragma unroll 4
-  for (int i = 0; i < kPartItems; ++i) {
-    const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
-    if (j < count) {
-      const uint32_t id = IMPLICIT ? row0 + j : src[row0 + j];
-      atomicAdd(&hist[key32(tb, (uint64_t)id + depth) >> 24], 1u);
+  uint32_t cur_seg = 0xFFFFFFFFu;
+  for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
+    const bool live = locate_tile_at(blockIdx.x * kHistTilesPerGroup + k, segs, tile_first, nsegs, ctr, &ti);
+    const uint32_t seg = live ? ti.seg : 0xFFFFFFFFu;
+    if (seg != cur_seg) {
+      if (cur_seg != 0xFFFFFFFFu) {
+        const uint32_t c = hist[threadIdx.x];
+        if (c) atomicAdd(&seg_counts[(uint64_t)cur_seg * 256 + threadIdx.x], c);
+        hist[threadIdx.x] = 0;
+      }
+      cur_seg = seg;
+      __syncthreads();
     }
+    if (!live) break;
+    const uint32_t row0 = ti.row0, count = ti.count;
+#pragma unroll 4
+    for (int i = 0; i < kPartItems; ++i) {
+      const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
+      if (j < count) {
+        uint32_t d;
+        if (MODE == 2) {
+          d = (srckey[row0 + j] >> 16) & 255u;
+        } else {
+          const uint32_t id = MODE == 0 ? row0 + j : src[row0 + j];
+          d = key32(tb, (uint64_t)id + depth) >> 24;
+        }
+        atomicAdd(&hist[d], 1u);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t c = hist[threadIdx.x];
-  if (c) atomicAdd(&seg_counts[(uint64_t)ti.seg * 256 + threadIdx.x], c);
+  if (cur_seg != 0xFFFFFFFFu) {
+    const uint32_t c = hist[threadIdx.x];
+    if (c) atomicAdd(&seg_counts[(uint64_t)cur_seg * 256 + threadIdx.x], c);
+  }
 }
 
 // One workgroup per segment: counts -> absolute cursors of the 256 children;
@@ -165,7 +200,8 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
 __global__ void __launch_bounds__(256)
 k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
                 uint32_t dst_id, Seg *__restrict__ next_segs, uint32_t next_cap,
-                Leaf *__restrict__ leaves, uint32_t leaf_cap, Counters *__restrict__ ctr) {
+                Leaf *__restrict__ leaves, uint32_t leaf_cap, uint32_t *__restrict__ leafmask,
+                Counters *__restrict__ ctr) {
   __shared__ uint32_t sizes[256], starts[256], wsum[4];
   const uint32_t s = blockIdx.x, t = threadIdx.x;
   const Seg sg = segs[s];
@@ -184,6 +220,14 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   seg_counts[(uint64_t)s * 256 + t] = start;  // becomes the scatter cursor
   sizes[t] = c;
   starts[t] = start;
+  {
+    // which children end in a leaf: the scatter fetches fresh sort keys for those only
+    const uint64_t small = __ballot(c <= kLeafMax);
+    if (lane == 0) {
+      leafmask[(uint64_t)s * 8 + wave * 2] = (uint32_t)small;
+      leafmask[(uint64_t)s * 8 + wave * 2 + 1] = (uint32_t)(small >> 32);
+    }
+  }
   __syncthreads();
   // greedy merge by one thread into LDS lists, then one reservation per list
   // and a parallel copy-out (a global atomic per record would serialise)
@@ -224,13 +268,20 @@ __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
 // Tile-local bucket order in LDS, then each bucket's run goes to the
 // segment's cursor for that bucket (one atomic per tile and bucket).  Order
 // inside a bucket is irrelevant at this stage.
+// IMPLICIT (level 0): ids are text positions, keys come from sequential text.
+// Otherwise the bucket of a suffix is read from the word the previous level
+// stored with it; a fresh 16-base key is gathered from the text only for
+// suffixes whose bucket ends in a leaf (or for all when the stored words have
+// been shifted twice already and hold no further level's bases).
 template <bool IMPLICIT>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
-               uint32_t *__restrict__ dst, uint32_t *__restrict__ dstkey,
-               const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
-               uint32_t depth, const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors) {
-  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4];
+               const uint32_t *__restrict__ srckey, uint32_t *__restrict__ dst,
+               uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
+               const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
+               const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors,
+               const uint32_t *__restrict__ leafmask, int gather_all) {
+  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4], lmask[8];
   __shared__ uint32_t ids[kPartTile];
   __shared__ uint32_t kv[kPartTile];
   __shared__ TileInfo ti;
@@ -239,15 +290,30 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   fill[t] = 0;
   if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
+  if (!IMPLICIT) {
+    if (t < 8) lmask[t] = gather_all ? 0xFFFFFFFFu : leafmask[(uint64_t)ti.seg * 8 + t];
+    __syncthreads();
+  }
   uint32_t id[kPartItems], key[kPartItems];
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
     const uint32_t j = (uint32_t)i * kPartThreads + t;
     if (j < count) {
-      id[i] = IMPLICIT ? row0 + j : src[row0 + j];
-      key[i] = key32(tb, (uint64_t)id[i] + depth);
-      atomicAdd(&hist[key[i] >> 24], 1u);
-      key[i] = carried_word(tb, id[i], key[i]);
+      if (IMPLICIT) {
+        id[i] = row0 + j;
+        const uint32_t k32 = key32(tb, (uint64_t)id[i] + depth);
+        atomicAdd(&hist[k32 >> 24], 1u);
+        key[i] = carried_word(tb, id[i], k32);
+      } else {
+        id[i] = src[row0 + j];
+        const uint32_t old = srckey[row0 + j];
+        const uint32_t d = (old >> 16) & 255u;
+        atomicAdd(&hist[d], 1u);
+        if ((lmask[d >> 5] >> (d & 31u)) & 1u)
+          key[i] = (key32(tb, (uint64_t)id[i] + depth) & ~3u) | (old & 3u);
+        else
+          key[i] = ((old & ~3u) << 8) | (old & 3u);
+      }
     }
   }
   __syncthreads();
@@ -761,7 +827,7 @@ static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0,
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, tile_first, leaves, ctr, scanws, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, ctr, scanws, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -786,6 +852,7 @@ static Layout layout_for(uint32_t n) {
   L.segs0 = take((size_t)L.seg_cap * sizeof(Seg));
   L.segs1 = take((size_t)L.seg_cap * sizeof(Seg));
   L.counts = take((size_t)L.seg_cap * 256 * 4);
+  L.leafmask = take((size_t)L.seg_cap * 8 * 4);
   L.tile_first = take(((size_t)L.seg_cap + 1) * 4);
   L.leaves = take((size_t)L.leaf_cap * sizeof(Leaf));
   L.ctr = take(sizeof(Counters));
@@ -812,6 +879,7 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   uint32_t *ghead = reinterpret_cast<uint32_t *>(ws + L.ghead);
   Seg *segs[2] = {reinterpret_cast<Seg *>(ws + L.segs0), reinterpret_cast<Seg *>(ws + L.segs1)};
   uint32_t *counts = reinterpret_cast<uint32_t *>(ws + L.counts);
+  uint32_t *leafmask = reinterpret_cast<uint32_t *>(ws + L.leafmask);
   uint32_t *tile_first = reinterpret_cast<uint32_t *>(ws + L.tile_first);
   Leaf *leaves = reinterpret_cast<Leaf *>(ws + L.leaves);
   Counters *ctr = reinterpret_cast<Counters *>(ws + L.ctr);
@@ -842,6 +910,7 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
     nsegs = 1;
   }
   int levels = 0;
+  int key_age = 0;  // levels since the words stored with the ids were read from the text
   while (nsegs > 0 && depth < kMaxDepth) {
     const uint32_t dst_id = src_id == kSrcA ? kSrcB : kSrcA;
     const uint32_t *src = src_id == kSrcA ? bufA : src_id == kSrcB ? bufB : nullptr;
@@ -855,21 +924,29 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
     BWT_HIP(hipMemsetAsync(counts, 0, (size_t)nsegs * 256 * 4, s));
     BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
     const unsigned tile_bound = (unsigned)((uint64_t)n / kPartTile + nsegs + 1);
+    const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
+    const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_hist", k_part_hist<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src,
-                 segs[cur], tile_first, nsegs, depth, ctr, counts);
+      BWT_LAUNCH("sa_part_hist", k_part_hist<0>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     } else {
-      BWT_LAUNCH("sa_part_hist", k_part_hist<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src,
-                 segs[cur], tile_first, nsegs, depth, ctr, counts);
+      // the word stored by the previous level holds this level's four bases
+      BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
-               dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, ctr);
+               dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1);
+      key_age = 0;
     } else {
+      // stored words shifted twice hold no bases for a further level: refresh all
+      const int gather_all = key_age >= 1;
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask,
+                 gather_all);
+      key_age = gather_all ? 0 : key_age + 1;
     }
     BWT_CHECK_LAUNCH();
     BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
