@@ -42,6 +42,10 @@ SIGNATURES = {
     "bwtgpu_index_rank_rows16": (C.c_int, [vp, vp]),
     "bwtgpu_index_rank_rows": (C.c_int, [vp, u32, vp]),
     "bwtgpu_index_device_bytes": (sz, [vp]),
+    "bwtgpu_mms": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
+    "bwtgpu_search_reads": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, vp, vp]),
+    "bwtgpu_mms_host": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp]),
+    "bwtgpu_search_reads_host": (C.c_int, [vp, vp, vp, u64, C.c_int, vp]),
     "bwtgpu_occ_batch": (C.c_int, [vp, vp, vp, u64, C.c_int, vp, vp]),
     "bwtgpu_lf_batch": (C.c_int, [vp, vp, u64, vp, vp]),
     "bwtgpu_sa_build_host": (C.c_int, [vp, u32, vp]),

@@ -1,0 +1,244 @@
+// Maximum-mappable-suffix search (mms, seqindex.c:314-351) and the anchor loop
+// of search_reads (search_reads.c:102-160), one read per lane.
+#include "common.hpp"
+#include "fm_device.hpp"
+
+namespace bwtgpu {
+
+struct CTab {
+  uint32_t c[5];
+};
+
+__device__ __forceinline__ uint32_t c_of(const CTab &C, uint32_t k) {
+  return k == 0 ? C.c[0] : k == 1 ? C.c[1] : k == 2 ? C.c[2] : k == 3 ? C.c[3] : C.c[4];
+}
+
+// C[c] + Occ(c, idx) through the per-symbol layout
+__device__ __forceinline__ uint32_t occ_sym(const IndexView &v, uint32_t c, uint32_t idx) {
+  const uint32_t j = idx - (idx > v.endloc);
+  uint32_t r;
+  const uint32_t b = div96(j, r);
+  return sym_count(reinterpret_cast<const uint4 *>(v.sym)[(uint64_t)c * v.nsym + b], r);
+}
+
+// all four C[d] + Occ(d, idx) from one 32-byte block
+__device__ __forceinline__ void occ_all(const IndexView &v, uint32_t idx, uint32_t out[4]) {
+  const uint32_t j = idx - (idx > v.endloc);
+  const IndexBlock *b = v.blocks + (j >> 6);
+  const uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
+  const uint64_t lo = b->lo, hi = b->hi, m = low_mask(j & 63u);
+  out[0] = occ.x + (uint32_t)__popcll(~lo & ~hi & m);
+  out[1] = occ.y + (uint32_t)__popcll(lo & ~hi & m);
+  out[2] = occ.z + (uint32_t)__popcll(~lo & hi & m);
+  out[3] = occ.w + (uint32_t)__popcll(lo & hi & m);
+}
+
+// mms (seqindex.c:314-351).  Symbols 0..3 are bases, 5 is N: trailing Ns are
+// skipped (:317-320), an inner N is read as the base with the most
+// occurrences in the current interval, lowest base on ties (:330-340).
+// A pattern made of Ns only (the reference reads before the buffer there)
+// returns its length with an empty interval.
+__device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int len,
+                                       uint32_t *sp_out, uint32_t *ep_out) {
+  int skips = 0;
+  while (len > 0 && pat[len - 1] == 5) {
+    --len;
+    ++skips;
+  }
+  if (len == 0) {
+    *sp_out = 0;
+    *ep_out = 0;
+    return skips;
+  }
+  uint32_t c = pat[len - 1] & 3u;
+  uint32_t start = c_of(C, c), end = c_of(C, c + 1);
+  uint32_t sp = start, ep = end;
+  int i;
+  for (i = len - 2; i >= 0; --i) {
+    if (end <= start) break;
+    sp = start;
+    ep = end;
+    const uint32_t raw = pat[i];
+    if (raw == 5) {
+      uint32_t a[4], b[4];
+      occ_all(v, start, a);
+      occ_all(v, end, b);
+      c = 0;
+      int64_t best = -1;
+      for (uint32_t d = 0; d < 4; ++d) {
+        const int64_t cnt = (int64_t)b[d] - (int64_t)a[d];
+        if (cnt > best) {
+          best = cnt;
+          c = d;
+        }
+      }
+      start = a[c];
+      end = b[c];
+    } else {
+      c = raw & 3u;
+      start = occ_sym(v, c, start);
+      end = occ_sym(v, c, end);
+    }
+  }
+  if (end <= start) {
+    *sp_out = sp;
+    *ep_out = ep;
+    return len - i - 2 + skips;
+  }
+  *sp_out = start;
+  *ep_out = end;
+  return len - i - 1 + skips;
+}
+
+// unc_sa (seqindex.c:244-255) for one row, in line
+__device__ __forceinline__ uint32_t unc_sa_dev(const IndexView &v, uint32_t idx) {
+  uint32_t steps = 0;
+  while (idx & 31u) {
+    idx = lf_step(v, idx);
+    ++steps;
+  }
+  uint64_t x = (uint64_t)v.idxs[idx >> 5] + steps;
+  if (x > v.n) x -= (uint64_t)v.n + 1;
+  return (uint32_t)x;
+}
+
+__global__ void __launch_bounds__(256)
+k_mms_batch(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride,
+            uint64_t R, int32_t *__restrict__ matched, uint32_t *__restrict__ d_sp,
+            uint32_t *__restrict__ d_ep) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  uint32_t sp, ep;
+  matched[r] = mms_dev(v, C, pats + r * stride, (int)m, &sp, &ep);
+  d_sp[r] = sp;
+  d_ep[r] = ep;
+}
+
+// The per-read loop of search_reads (search_reads.c:115-153) on an encoded
+// read and on its reverse: repeatedly take the maximum mappable suffix; an
+// anchor of at least `anchor` bases counts, is located (unc_sa of the first
+// row of its interval) and is cut off, otherwise one base is cut off.
+// out[4r..4r+3] = forward anchors, backward anchors, last forward position,
+// last backward position (positions 0xFFFFFFFF when there was no anchor).
+__global__ void __launch_bounds__(256)
+k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
+               const uint8_t *__restrict__ reversed, const uint64_t *__restrict__ offsets,
+               uint64_t R, int anchor, uint32_t *__restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint64_t o = offsets[r];
+  const int full = (int)(offsets[r + 1] - o);
+  uint32_t res[4] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (int dir = 0; dir < 2; ++dir) {
+    const uint8_t *p = (dir ? reversed : reads) + o;
+    int len = full;
+    while (len > anchor) {  // search_reads.c:115
+      uint32_t sp, ep;
+      const int got = mms_dev(v, C, p, len, &sp, &ep);
+      if (got >= anchor) {  // :119-127
+        res[dir]++;
+        len -= got;
+        res[2 + dir] = sp <= v.n ? unc_sa_dev(v, sp) : 0xFFFFFFFFu;
+      } else {
+        len -= 1;  // :130
+      }
+    }
+  }
+  reinterpret_cast<uint4 *>(out)[r] = make_uint4(res[0], res[1], res[2], res[3]);
+}
+
+}  // namespace bwtgpu
+
+using namespace bwtgpu;
+
+extern "C" {
+
+int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride, uint64_t R,
+               int32_t *d_matched, uint32_t *d_sp, uint32_t *d_ep, void *stream) {
+  if (!ix || !d_pats || !d_matched || !d_sp || !d_ep) return set_error(kErrArg, "null argument");
+  if (m == 0 || m > 0x7FFFFFFFu) return set_error(kErrArg, "pattern length out of range");
+  if (R == 0) return kOk;
+  CTab C;
+  for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+  BWT_LAUNCH("fm_mms", k_mms_batch, dim3((unsigned)div_up(R, 256)), dim3(256), 0, (hipStream_t)stream,
+             view_of(ix), C, d_pats, m, stride, R, d_matched, d_sp, d_ep);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads, const uint8_t *d_reversed,
+                        const uint64_t *d_offsets, uint64_t R, int anchor, uint32_t *d_out,
+                        void *stream) {
+  if (!ix || !d_reads || !d_reversed || !d_offsets || !d_out) return set_error(kErrArg, "null argument");
+  if (anchor < 1) return set_error(kErrArg, "anchor length must be positive");
+  if (R == 0) return kOk;
+  CTab C;
+  for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+  BWT_LAUNCH("fm_search_reads", k_search_reads, dim3((unsigned)div_up(R, 256)), dim3(256), 0,
+             (hipStream_t)stream, view_of(ix), C, d_reads, d_reversed, d_offsets, R, anchor, d_out);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+int bwtgpu_mms_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride,
+                    uint64_t R, int32_t *h_matched, uint32_t *h_sp, uint32_t *h_ep) {
+  if (!ix || !h_pats || !h_matched || !h_sp || !h_ep) return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  void *pats = nullptr, *out = nullptr;
+  const size_t pb = (R - 1) * stride + m;
+  hipError_t e = hipMalloc(&pats, pb);
+  if (e == hipSuccess) e = hipMalloc(&out, R * 12);
+  int rc = kOk;
+  if (e != hipSuccess) {
+    rc = set_error(kErrHip, "mms buffers: %s", hipGetErrorString(e));
+  } else {
+    int32_t *dm = (int32_t *)out;
+    uint32_t *ds = (uint32_t *)out + R, *de = (uint32_t *)out + 2 * R;
+    e = hipMemcpy(pats, h_pats, pb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) rc = bwtgpu_mms(ix, (const uint8_t *)pats, m, stride, R, dm, ds, de, nullptr);
+    if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_matched, dm, R * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_sp, ds, R * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_ep, de, R * 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_error(kErrHip, "mms copies: %s", hipGetErrorString(e));
+  }
+  if (pats) (void)hipFree(pats);
+  if (out) (void)hipFree(out);
+  return rc;
+}
+
+int bwtgpu_search_reads_host(const bwtgpu_index *ix, const uint8_t *h_reads, const uint64_t *h_offsets,
+                             uint64_t R, int anchor, uint32_t *h_out) {
+  if (!ix || !h_reads || !h_offsets || !h_out) return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint64_t total = h_offsets[R];
+  uint8_t *rev = (uint8_t *)malloc(total ? total : 1);
+  if (!rev) return set_error(kErrArg, "out of host memory");
+  for (uint64_t r = 0; r < R; ++r) {  // search_reads.c:112-114: plain reversal
+    const uint64_t a = h_offsets[r], b = h_offsets[r + 1];
+    for (uint64_t k = 0; k < b - a; ++k) rev[a + k] = h_reads[b - 1 - k];
+  }
+  void *d_reads = nullptr, *d_rev = nullptr, *d_off = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_reads, total + 16);
+  if (e == hipSuccess) e = hipMalloc(&d_rev, total + 16);
+  if (e == hipSuccess) e = hipMalloc(&d_off, (R + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc(&d_out, R * 16);
+  int rc = kOk;
+  if (e == hipSuccess) e = hipMemcpy(d_reads, h_reads, total, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_rev, rev, total, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_off, h_offsets, (R + 1) * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    rc = bwtgpu_search_reads(ix, (const uint8_t *)d_reads, (const uint8_t *)d_rev, (const uint64_t *)d_off,
+                             R, anchor, (uint32_t *)d_out, nullptr);
+  if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_out, d_out, R * 16, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = set_error(kErrHip, "search_reads buffers: %s", hipGetErrorString(e));
+  free(rev);
+  if (d_reads) (void)hipFree(d_reads);
+  if (d_rev) (void)hipFree(d_rev);
+  if (d_off) (void)hipFree(d_off);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+}  // extern "C"

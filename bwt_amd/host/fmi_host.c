@@ -473,6 +473,49 @@ int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos)
   return 0;
 }
 
+int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                  int *matched, int *sp, int *ep) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_mms_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
+                      matched, (uint32_t *)sp, (uint32_t *)ep)) {
+    report("mms");
+    return -1;
+  }
+  return 0;
+}
+
+int mms(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep) {
+  int matched = 0;
+  if (fmi_mms_batch(fmi, pattern, len, len, 1, &matched, sp, ep)) return 0;
+  return matched;
+}
+
+int fmi_search_reads_batch(const fm_index *fmi, const char *reads, const unsigned long *offsets,
+                           long nreads, int anchor, int *out) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_search_reads_host(ix, (const uint8_t *)reads, (const uint64_t *)offsets, (uint64_t)nreads,
+                               anchor, (uint32_t *)out)) {
+    report("search_reads");
+    return -1;
+  }
+  return 0;
+}
+
+void fmi_encode_read(const char *ascii, long len, char *out) {
+  /* single_align.c:450-474 */
+  for (long i = 0; i < len; ++i) {
+    switch (ascii[i]) {
+      case 'A': out[i] = 0; break;
+      case 'C': out[i] = 1; break;
+      case 'G': out[i] = 2; break;
+      case 'T': out[i] = 3; break;
+      default: out[i] = 5;
+    }
+  }
+}
+
 /* ------------------------------------------------------------------ */
 /* genome packer                                                       */
 /* ------------------------------------------------------------------ */

@@ -115,6 +115,24 @@ size_t bwtgpu_locate_workspace_bytes(void);
 int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R,
                        uint32_t *d_pos, unsigned long long *d_steps,
                        void *d_ws, size_t ws_bytes, void *stream);
+/* Replaces the host loop over mms (seqindex.c:314-351): maximum mappable
+ * suffix of each read; symbols 0..3 are bases, 5 is N (trailing Ns skipped,
+ * an inner N read as the most frequent base of the current interval).
+ * d_matched[r] is mms's return value, d_sp/d_ep the interval it stores.  A read
+ * of Ns only returns its length and an empty interval (the reference reads
+ * before the buffer there).  Patterns are read byte-wise, no workspace. */
+int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+               uint64_t R, int32_t *d_matched, uint32_t *d_sp, uint32_t *d_ep, void *stream);
+/* Replaces the per-read body of search_reads (search_reads.c:115-153): read r
+ * is the encoded bytes d_reads[d_offsets[r] .. d_offsets[r+1]) (0..3, 5 = N),
+ * d_reversed holds each read reversed in the same slots (search_reads.c:112-114).
+ * d_out[4r..4r+3] = forward anchors, backward anchors, position of the last
+ * forward anchor, of the last backward anchor (0xFFFFFFFF: none); an anchor is
+ * a maximum mappable suffix of at least `anchor` bases (20 in the reference). */
+int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads,
+                        const uint8_t *d_reversed, const uint64_t *d_offsets, uint64_t R,
+                        int anchor, uint32_t *d_out, void *stream);
+
 /* Occ(c, idx) for R (symbol, index) pairs: seq_rank (seqindex.c:91-111) when
  * skip_dollar_row is 0, rank (seqindex.c:221-225) when it is 1.  Indices
  * beyond n give 0xFFFFFFFF. */
@@ -142,6 +160,11 @@ int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint
 int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *h_idx,
                     uint64_t R, int skip_dollar_row, uint32_t *h_out);
 int bwtgpu_lf_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R, uint32_t *h_out);
+int bwtgpu_mms_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride,
+                    uint64_t R, int32_t *h_matched, uint32_t *h_sp, uint32_t *h_ep);
+/* reverses the reads itself */
+int bwtgpu_search_reads_host(const bwtgpu_index *ix, const uint8_t *h_reads,
+                             const uint64_t *h_offsets, uint64_t R, int anchor, uint32_t *h_out);
 
 /* ---- seeded synthetic inputs, generated in HBM (bench/test plumbing) ---- */
 /* Bit-identical to the host generators in bwt_amd/synth.py. */

@@ -69,6 +69,7 @@ int reverse_search(const fm_index *fmi, const char *pattern, int len);          
 int unc_sa(const fm_index *fmi, int idx);                                       /* seqindex.c:244-255 */
 int locate(const fm_index *fmi, const char *pattern, int len);                  /* seqindex.c:258-277 */
 void loc_search(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep); /* seqindex.c:280-309 */
+int mms(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep);    /* seqindex.c:314-351 */
 void printseq(const char *seq, int startidx, int len);                          /* seqindex.c:354-360 */
 
 /* ---- fileio.h:4-6 / fileio.c:8-65: byte-identical index files ---- */
@@ -89,6 +90,19 @@ int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride
                      long nreads, int *pos);
 /* unc_sa per row */
 int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos);
+
+/* mms per read (symbols 0..3, 5 = N): matched[r], sp[r], ep[r] */
+int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                  int *matched, int *sp, int *ep);
+/* The per-read body of search_reads (search_reads.c:102-160) for nreads reads
+ * stored back to back, read r at reads[offsets[r] .. offsets[r+1]), encoded
+ * 0..3 / 5 (fmi_encode_read).  out[4r..4r+3] = forward anchors, backward
+ * anchors, last forward position, last backward position (-1: none). */
+int fmi_search_reads_batch(const fm_index *fmi, const char *reads, const unsigned long *offsets,
+                           long nreads, int anchor, int *out);
+/* ASCII -> symbols as single_align.c:450-474 encodes reads: A C G T -> 0 1 2 3,
+ * anything else -> 5 */
+void fmi_encode_read(const char *ascii, long len, char *out);
 
 /* the genome packer of build_index.c:54-87 / search_reads.c:47-80 (tail quirk
  * included: the last len%4 bases read as A); out holds len/4+1 bytes */

@@ -111,6 +111,7 @@ class Oracle:
         L.orc_locate.restype = C.c_int64
         L.orc_locate.argtypes = [fp, u8p, C.c_int]
         L.orc_mms.argtypes = [fp, u8p, C.c_int, u32p, u32p]
+        L.orc_search_reads_one.argtypes = [fp, u8p, C.c_int, C.c_int, u32p]
         L.orc_search_batch.argtypes = [fp, u8p, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, C.c_int]
         L.orc_locate_rows.argtypes = [fp, u32p, C.c_uint64, u32p, C.POINTER(C.c_uint64), C.c_int]
         L.orc_write_index_path.argtypes = [fp, C.c_char_p]
@@ -207,6 +208,12 @@ class Oracle:
         sp, ep = C.c_uint32(), C.c_uint32()
         k = self.L.orc_mms(f.ptr, _p(pat, u8p), len(pat), C.byref(sp), C.byref(ep))
         return int(k), sp.value, ep.value
+
+    def search_reads_one(self, f, read, anchor=20):
+        read = np.ascontiguousarray(read, np.uint8)
+        out = np.zeros(4, np.uint32)
+        self.L.orc_search_reads_one(f.ptr, _p(read, u8p), len(read), anchor, _p(out, u32p))
+        return out
 
     def search_batch(self, f, pats, m, stride, R, threads=4):
         pats = np.ascontiguousarray(pats, np.uint8)

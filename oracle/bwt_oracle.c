@@ -485,6 +485,34 @@ int orc_mms(const orc_fmi *f, const uint8_t *pat, int m, uint32_t *sp,
   return m - i - 1 + skips;
 }
 
+void orc_search_reads_one(const orc_fmi *f, const uint8_t *read, int len, int anchor,
+                          uint32_t out[4]) {
+  /* search_reads.c:102-160 on an encoded read (0..3, 5 = N; the shipped
+   * program passes raw ASCII to mms, which indexes C[] out of bounds, so the
+   * read encoding of single_align.c:450-474 is used instead); the second pass
+   * runs on the plain reversal of the read (search_reads.c:112-114) */
+  uint8_t *rev = malloc(len ? len : 1);
+  for (int k = 0; k < len; ++k) rev[k] = read[len - 1 - k];
+  out[0] = out[1] = 0;
+  out[2] = out[3] = 0xFFFFFFFFu;
+  for (int dir = 0; dir < 2; ++dir) {
+    const uint8_t *p = dir ? rev : read;
+    int l = len;
+    while (l > anchor) {
+      uint32_t sp, ep;
+      int got = orc_mms(f, p, l, &sp, &ep);
+      if (got >= anchor) {
+        out[dir]++;
+        l -= got;
+        out[2 + dir] = sp <= f->len ? orc_unc_sa(f, sp, NULL) : 0xFFFFFFFFu;
+      } else {
+        l -= 1;
+      }
+    }
+  }
+  free(rev);
+}
+
 /* ---- threaded batch drivers (fmitest.c:54-91: static contiguous split) ---- */
 
 typedef struct {

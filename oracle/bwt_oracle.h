@@ -100,6 +100,12 @@ int64_t  orc_locate(const orc_fmi *f, const uint8_t *pat, int m);
 int      orc_mms(const orc_fmi *f, const uint8_t *pat, int m,
                  uint32_t *sp, uint32_t *ep);                     /* seqindex.c:314-351 */
 
+/* the per-read body of search_reads (search_reads.c:102-160) on an encoded
+ * read: out = forward anchors, backward anchors, last forward position, last
+ * backward position (0xFFFFFFFF: none) */
+void orc_search_reads_one(const orc_fmi *f, const uint8_t *read, int len, int anchor,
+                          uint32_t out[4]);
+
 /* batch drivers used for cpu_baseline timing: threads pthreads, each a
  * contiguous slice (fmitest.c:67-91) */
 void orc_search_batch(const orc_fmi *f, const uint8_t *pats, uint32_t m,
