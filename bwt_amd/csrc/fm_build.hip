@@ -72,7 +72,7 @@ k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__
 __global__ void k_sample_sa(const uint32_t *__restrict__ sa, uint64_t nsamples,
                             uint32_t *__restrict__ idxs) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nsamples) idxs[i] = sa[32 * i];
+  if (i < nsamples) idxs[i] = sa[i << kDevSampleShift];
 }
 
 // sprintcbwt's own output format: four bases per byte, first base in the top
@@ -166,7 +166,7 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
       BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0,
                  s, d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
     }
-    const uint64_t ns = (uint64_t)n / 32 + 1;
+    const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns,
                ix->d_idxs);
     e = hipGetLastError();

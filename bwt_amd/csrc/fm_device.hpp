@@ -54,9 +54,9 @@ __device__ __forceinline__ uint32_t sym_count(const uint4 &b, uint32_t r) {
   return b.x + (uint32_t)__popcll(lo64 & mlo) + (uint32_t)__popc(b.w & mhi);
 }
 
-// LF mapping (seqindex.c:214-219) for a row in [0, n].
+// LF mapping (seqindex.c:214-219) for a row in [0, n].  Branch-free so that
+// several independent walks in one lane keep their loads in flight together.
 __device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx) {
-  if (idx == v.endloc) return 0;
   const uint32_t j = idx - (idx > v.endloc);
   const IndexBlock *b = v.blocks + (j >> 6);
   const uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
@@ -66,7 +66,8 @@ __device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx) {
   const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
   const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(r);
   const uint32_t base = c == 0 ? occ.x : c == 1 ? occ.y : c == 2 ? occ.z : occ.w;
-  return base + (uint32_t)__popcll(match);
+  const uint32_t next = base + (uint32_t)__popcll(match);
+  return idx == v.endloc ? 0u : next;  // the $ row maps to row 0
 }
 
 }  // namespace bwtgpu

@@ -284,6 +284,29 @@ __global__ void k_build_sym(const IndexBlock *__restrict__ blocks, uint64_t nblo
   }
 }
 
+// Stored samples (every 32nd row) -> HBM samples (every 8th): rows that the
+// file has are copied, the others are found by the walk unc_sa itself does
+// (seqindex.c:244-255) down to the next stored row.
+__global__ void k_densify_samples(IndexView v, const uint32_t *__restrict__ stored, uint64_t ndense,
+                                  uint32_t *__restrict__ dense) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= ndense) return;
+  uint32_t idx = (uint32_t)(q << kDevSampleShift), steps = 0;
+  while (idx & ((1u << kFileSampleShift) - 1u)) {
+    idx = lf_step(v, idx);
+    ++steps;
+  }
+  uint64_t x = (uint64_t)stored[idx >> kFileSampleShift] + steps;
+  if (x > v.n) x -= (uint64_t)v.n + 1;
+  dense[q] = (uint32_t)x;
+}
+
+__global__ void k_thin_samples(const uint32_t *__restrict__ dense, uint64_t nstored,
+                               uint32_t *__restrict__ stored) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nstored) stored[i] = dense[i << (kFileSampleShift - kDevSampleShift)];
+}
+
 int index_alloc(bwtgpu_index **out, uint32_t n) {
   if (n == 0 || n > 0xFFFFFFF0u)
     return set_error(kErrArg, "text length %u out of range", n);
@@ -294,7 +317,8 @@ int index_alloc(bwtgpu_index **out, uint32_t n) {
   BWT_HIP(hipGetDevice(&ix->device));
   hipError_t e = hipMalloc(&ix->d_blocks, ix->nblocks * sizeof(IndexBlock));
   if (e == hipSuccess) e = hipMalloc(&ix->d_sym, 4 * ix->nsym * sizeof(SymBlock));
-  if (e == hipSuccess) e = hipMalloc(&ix->d_idxs, ((uint64_t)n / 32 + 1) * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = hipMalloc(&ix->d_idxs, (((uint64_t)n >> kDevSampleShift) + 1) * sizeof(uint32_t));
   if (e != hipSuccess) {
     bwtgpu_index_free(ix);
     return set_error(kErrHip, "hipMalloc of index for n=%u failed: %s", n, hipGetErrorString(e));
@@ -359,9 +383,11 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
   const uint64_t nb = ix->nblocks;
   const size_t bwt_bytes = ((size_t)n + 3) / 4;
   uint8_t *d_bwt = nullptr;
+  uint32_t *d_stored = nullptr;
   auto fail = [&](hipError_t e, const char *what) {
     set_error(kErrHip, "%s: %s", what, hipGetErrorString(e));
     if (d_bwt) (void)hipFree(d_bwt);
+    if (d_stored) (void)hipFree(d_stored);
     bwtgpu_index_free(ix);
     return (bwtgpu_index *)nullptr;
   };
@@ -369,9 +395,11 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
   if (e != hipSuccess) return fail(e, "hipMalloc bwt staging");
   e = hipMemsetAsync(d_bwt, 0, nb * 16, s);
   if (e == hipSuccess) e = hipMemcpyAsync(d_bwt, h_bwt, bwt_bytes, hipMemcpyHostToDevice, s);
+  const size_t nstored = (size_t)n / 32 + 1, ndense = ((size_t)n >> kDevSampleShift) + 1;
+  if (e == hipSuccess) e = hipMalloc(&d_stored, nstored * 4);
   if (e == hipSuccess)
-    e = h_idxs ? hipMemcpyAsync(ix->d_idxs, h_idxs, ((size_t)n / 32 + 1) * 4, hipMemcpyHostToDevice, s)
-               : hipMemsetAsync(ix->d_idxs, 0, ((size_t)n / 32 + 1) * 4, s);
+    e = h_idxs ? hipMemcpyAsync(d_stored, h_idxs, nstored * 4, hipMemcpyHostToDevice, s)
+               : hipMemsetAsync(ix->d_idxs, 0, ndense * 4, s);
   if (e != hipSuccess) return fail(e, "index upload");
   {
     ScopedKernelTimer t("bwt_to_planes", s);
@@ -379,7 +407,14 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
                        reinterpret_cast<const uint4 *>(d_bwt), ix->d_blocks, nb, n);
   }
   int rc = index_finish_from_planes(ix, s);
+  if (rc == kOk && h_idxs) {
+    ScopedKernelTimer t("densify_samples", s);
+    hipLaunchKernelGGL(k_densify_samples, dim3((unsigned)div_up(ndense, 256)), dim3(256), 0, s,
+                       view_of(ix), d_stored, (uint64_t)ndense, ix->d_idxs);
+  }
+  if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "sample densify failed");
   (void)hipFree(d_bwt);
+  if (d_stored) (void)hipFree(d_stored);
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return nullptr;
@@ -399,14 +434,23 @@ int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc, uin
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
-         ((size_t)ix->n / 32 + 1) * 4;
+         (((size_t)ix->n >> kDevSampleShift) + 1) * 4;
 }
 
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {
   if (!ix) return set_error(kErrArg, "null index");
   BWT_HIP(hipSetDevice(ix->device));
-  if (h_idxs)
-    BWT_HIP(hipMemcpy(h_idxs, ix->d_idxs, ((size_t)ix->n / 32 + 1) * 4, hipMemcpyDeviceToHost));
+  if (h_idxs) {
+    // the stored form keeps every 32nd row (fileio.c:14)
+    const uint64_t nstored = (uint64_t)ix->n / 32 + 1;
+    uint32_t *d_stored = nullptr;
+    BWT_HIP(hipMalloc(&d_stored, nstored * 4));
+    BWT_LAUNCH("thin_samples", k_thin_samples, dim3((unsigned)div_up(nstored, 256)), dim3(256), 0, nullptr,
+               ix->d_idxs, nstored, d_stored);
+    hipError_t e = hipMemcpy(h_idxs, d_stored, nstored * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_stored);
+    if (e != hipSuccess) return set_error(kErrHip, "sample export: %s", hipGetErrorString(e));
+  }
   if (h_bwt) {
     uint4 *d_bwt = nullptr;
     BWT_HIP(hipMalloc(&d_bwt, ix->nblocks * 16));

@@ -93,11 +93,11 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
 // unc_sa (seqindex.c:244-255) for one row, in line
 __device__ __forceinline__ uint32_t unc_sa_dev(const IndexView &v, uint32_t idx) {
   uint32_t steps = 0;
-  while (idx & 31u) {
+  while (idx & kDevSampleMask) {
     idx = lf_step(v, idx);
     ++steps;
   }
-  uint64_t x = (uint64_t)v.idxs[idx >> 5] + steps;
+  uint64_t x = (uint64_t)v.idxs[idx >> kDevSampleShift] + steps;
   if (x > v.n) x -= (uint64_t)v.n + 1;
   return (uint32_t)x;
 }

@@ -105,24 +105,40 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
 }
 
 constexpr uint32_t kLocateBatch = 256;  // rows a wave takes from the queue at a time
+constexpr int kLocateSlots = 2;         // independent walks per lane
 
 // unc_sa (seqindex.c:244-255) for a batch of rows.  The walk length is
-// geometric (a row is sampled when row % 32 == 0), so lanes do not run one row
-// each to the end: a lane that finishes takes the next row from its wave's
-// share of a global queue, which keeps all 64 lanes walking.
+// geometric (a row is sampled when row % 8 == 0 in HBM), so lanes do not run one row
+// each to the end: a slot that finishes takes the next row from its wave's
+// share of a global queue, which keeps every lane walking.  Each lane runs
+// kLocateSlots walks at once: a walk is a chain of dependent 32-byte reads, and
+// independent chains are what hides their latency.
 __global__ void __launch_bounds__(256)
 k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *__restrict__ pos,
          unsigned long long *__restrict__ steps_total, unsigned long long *__restrict__ queue_head) {
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t loc_lo = 0, loc_hi = 0;  // wave-uniform: rows this wave holds
   bool exhausted = false;           // wave-uniform: the queue has run dry
-  bool active = false;
-  uint32_t idx = 0, steps = 0;
-  uint64_t mine = 0;
+  bool active[kLocateSlots];
+  uint32_t idx[kLocateSlots], steps[kLocateSlots];
+  uint64_t mine[kLocateSlots];
+#pragma unroll
+  for (int s = 0; s < kLocateSlots; ++s) {
+    active[s] = false;
+    idx[s] = 0;
+    steps[s] = 0;
+    mine[s] = 0;
+  }
   unsigned long long my_steps = 0;
   for (;;) {
-    const uint64_t need = __ballot(!active);
-    if (need) {
+    uint64_t need[kLocateSlots];
+    uint32_t want = 0;
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) {
+      need[s] = __ballot(!active[s]);
+      want += (uint32_t)__popcll(need[s]);
+    }
+    if (want) {
       if (loc_lo >= loc_hi && !exhausted) {
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(queue_head, (unsigned long long)kLocateBatch);
@@ -135,37 +151,54 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
           loc_hi = base + kLocateBatch < R ? base + kLocateBatch : R;
         }
       }
-      if (!active) {
-        const uint64_t cand = loc_lo + (uint64_t)__popcll(need & low_mask(lane));
-        if (cand < loc_hi) {
-          const uint32_t row = rows[cand];
-          if (row > v.n) {
-            pos[cand] = 0xFFFFFFFFu;
-          } else {
-            mine = cand;
-            idx = row;
-            steps = 0;
-            active = true;
+      uint64_t first = loc_lo;
+#pragma unroll
+      for (int s = 0; s < kLocateSlots; ++s) {
+        if (!active[s]) {
+          const uint64_t cand = first + (uint64_t)__popcll(need[s] & low_mask(lane));
+          if (cand < loc_hi) {
+            const uint32_t row = rows[cand];
+            if (row > v.n) {
+              pos[cand] = 0xFFFFFFFFu;
+            } else {
+              mine[s] = cand;
+              idx[s] = row;
+              steps[s] = 0;
+              active[s] = true;
+            }
           }
         }
+        first += (uint64_t)__popcll(need[s]);
       }
-      const uint64_t taken = (uint64_t)__popcll(need);
-      loc_lo = loc_lo + taken < loc_hi ? loc_lo + taken : loc_hi;
+      loc_lo = first < loc_hi ? first : loc_hi;
     }
-    if (!__any(active)) {
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) any = any || active[s];
+    if (!__any(any)) {
       if (exhausted && loc_lo >= loc_hi) break;
       continue;
     }
-    if (active) {
-      if ((idx & 31u) == 0) {
-        uint64_t x = (uint64_t)v.idxs[idx >> 5] + steps;
+    // walks that reached a sampled row finish; the others take one LF step,
+    // all loads of the lane issued before any result is used
+    bool step[kLocateSlots];
+    uint32_t nxt[kLocateSlots];
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) {
+      step[s] = active[s] && (idx[s] & kDevSampleMask);
+      nxt[s] = lf_step(v, step[s] ? idx[s] : 0u);
+    }
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) {
+      if (active[s] && !step[s]) {
+        uint64_t x = (uint64_t)v.idxs[idx[s] >> kDevSampleShift] + steps[s];
         if (x > v.n) x -= (uint64_t)v.n + 1;  // seqindex.c:252-253
-        pos[mine] = (uint32_t)x;
-        my_steps += steps;
-        active = false;
-      } else {
-        idx = lf_step(v, idx);
-        ++steps;
+        pos[mine[s]] = (uint32_t)x;
+        my_steps += steps[s];
+        active[s] = false;
+      } else if (step[s]) {
+        idx[s] = nxt[s];
+        ++steps[s];
       }
     }
   }
@@ -229,7 +262,7 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
   BWT_HIP(hipMemsetAsync(head, 0, 256, s));
   // enough waves to fill the chip (256 CUs x 8 waves/SIMD x 4 SIMDs), no more
   // than there are batches of rows
-  uint64_t waves = div_up(R, kLocateBatch);
+  uint64_t waves = div_up(R, (uint64_t)kLocateBatch);
   uint64_t groups = div_up(waves, 4);
   if (groups > 256 * 8) groups = 256 * 8;
   BWT_LAUNCH("fm_locate", k_locate, dim3((unsigned)groups), dim3(256), 0, s, view_of(ix), d_rows, R,

@@ -99,8 +99,11 @@ def test_locate_every_row_is_the_suffix_array(oracle, gpu, n):
     rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
     pos, steps = ix.locate_rows(rows, count_steps=True)
     np.testing.assert_array_equal(gpu.to_numpy_u32(pos), sa)
+    # HBM keeps every 8th row, the file every 32nd: same answers, shorter walks
     _, steps_o = oracle.locate_rows(fo, np.arange(n + 1, dtype=np.uint32))
-    assert steps == steps_o
+    assert steps <= steps_o
+    if n > 1000:
+        assert 5.0 < steps / (n + 1) < 9.0
 
 
 def test_locate_skips_invalid_rows(oracle, gpu):
