@@ -122,6 +122,14 @@ struct bwtgpu_index {
   uint64_t nsym = 0;     // blocks per symbol in d_sym: n/96 + 1
   bwtgpu::SymBlock *d_sym = nullptr;  // [4][nsym]
   uint32_t *d_idxs = nullptr;  // 1 + n/8 sampled SA rows: SA[8 i]
+  // Optional, kept when the index was built from the text and HBM allows
+  // (8.25 more bytes per base): the whole suffix array, its inverse, and the
+  // text as 16-base little-endian words behind one guard word.  With them a
+  // search finishes by comparing the read with the text once its interval is a
+  // single row, and locate is one lookup.
+  uint32_t *d_sa = nullptr;     // n+1 rows
+  uint32_t *d_isa = nullptr;    // n+1 positions -> row
+  uint32_t *d_text2 = nullptr;  // [0] guard, [1 + w] = bases 16w..16w+15, base k at bits 2k
   int device = 0;
 };
 

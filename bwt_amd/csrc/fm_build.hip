@@ -2,6 +2,8 @@
 // (sprintcbwt, histsortcomp.c:220-250), every 32nd SA row (seqindex.c:173-176),
 // rank blocks and C[] (seq_index, seqindex.c:23-87, :183-187).  The suffix
 // array stays in HBM; only what write_index stores ever goes to the host.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "fm_device.hpp"
 
@@ -67,6 +69,30 @@ k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__
     blocks[b].lo = lo;
     blocks[b].hi = hi;
   }
+}
+
+__global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
+                             uint32_t *__restrict__ isa) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < rows) isa[sa[j]] = (uint32_t)j;
+}
+
+// text as 16-base words with base k at bits 2k (the layout of packed reads),
+// one zero guard word in front, zeros from base n on
+__global__ void k_make_text2(const uint8_t *__restrict__ text, uint32_t n, uint64_t nwords,
+                             uint32_t *__restrict__ text2) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint32_t out = 0;
+  if (w >= 1) {
+    const uint64_t first = 16 * (w - 1);
+    const uint64_t nbytes = (uint64_t)n / 4 + 1;
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint64_t p = first + k;
+      if (p < n && (p >> 2) < nbytes) out |= text_base(text, p) << (2 * k);
+    }
+  }
+  text2[w] = out;
 }
 
 __global__ void k_sample_sa(const uint32_t *__restrict__ sa, uint64_t nsamples,
@@ -141,12 +167,26 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   bwtgpu_index *ix = nullptr;
   BWT_TRY(index_alloc(&ix, n));
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
-  int rc = cache_reserve(((size_t)n + 1) * 4, ws_bytes);
+  // keep SA, ISA and the text in the index unless asked not to or HBM is short
+  const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  if (!getenv("BWT_MI355X_COMPACT")) {
+    hipError_t ea = hipMalloc(&ix->d_sa, rows_all * 4);
+    if (ea == hipSuccess) ea = hipMalloc(&ix->d_isa, rows_all * 4);
+    if (ea == hipSuccess) ea = hipMalloc(&ix->d_text2, t2words * 4);
+    if (ea != hipSuccess) {
+      (void)hipGetLastError();
+      if (ix->d_sa) (void)hipFree(ix->d_sa);
+      if (ix->d_isa) (void)hipFree(ix->d_isa);
+      if (ix->d_text2) (void)hipFree(ix->d_text2);
+      ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+    }
+  }
+  int rc = cache_reserve(ix->d_sa ? 256 : ((size_t)n + 1) * 4, ws_bytes);
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return rc;
   }
-  uint32_t *d_sa = reinterpret_cast<uint32_t *>(g_cache.sa);
+  uint32_t *d_sa = ix->d_sa ? ix->d_sa : reinterpret_cast<uint32_t *>(g_cache.sa);
   void *d_ws = g_cache.ws;
   uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
   auto cleanup = [&]() {};
@@ -169,6 +209,12 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
     const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns,
                ix->d_idxs);
+    if (ix->d_sa) {
+      BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows_all, 256)), dim3(256), 0, s, d_sa,
+                 rows_all, ix->d_isa);
+      BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text,
+                 n, t2words, ix->d_text2);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) rc = set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));

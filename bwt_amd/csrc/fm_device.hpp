@@ -10,13 +10,17 @@ struct IndexView {
   const IndexBlock *blocks;
   const SymBlock *sym;
   const uint32_t *idxs;
+  const uint32_t *sa;     // null unless the index keeps the whole suffix array
+  const uint32_t *isa;
+  const uint32_t *text2;
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
 };
 
 inline IndexView view_of(const bwtgpu_index *ix) {
-  return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->nsym, ix->n, ix->endloc};
+  return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa, ix->d_isa, ix->d_text2,
+                   ix->nsym,     ix->n,     ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {

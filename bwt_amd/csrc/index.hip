@@ -363,6 +363,9 @@ void bwtgpu_index_free(bwtgpu_index *ix) {
   if (ix->d_blocks) (void)hipFree(ix->d_blocks);
   if (ix->d_sym) (void)hipFree(ix->d_sym);
   if (ix->d_idxs) (void)hipFree(ix->d_idxs);
+  if (ix->d_sa) (void)hipFree(ix->d_sa);
+  if (ix->d_isa) (void)hipFree(ix->d_isa);
+  if (ix->d_text2) (void)hipFree(ix->d_text2);
   delete ix;
 }
 
@@ -434,7 +437,8 @@ int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc, uin
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
-         (((size_t)ix->n >> kDevSampleShift) + 1) * 4;
+         (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
+         (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0);
 }
 
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {

@@ -67,9 +67,26 @@ struct CTable {
   uint32_t c[5];
 };
 
+// 16 bases of text starting at position o (o >= -15), base k of the result at
+// bits 2k; text2[0] is a guard word so that o may reach 15 below zero.
+__device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, int64_t o) {
+  const uint64_t q = (uint64_t)(o + 16);
+  const uint64_t both = ((uint64_t)text2[(q >> 4) + 1] << 32) | text2[q >> 4];
+  return (uint32_t)(both >> (2u * (uint32_t)(q & 15u)));
+}
+
 // Backward search (loc_search, seqindex.c:280-309), one read per lane.
 // d_locrow (optional) receives the row locate() would hand to unc_sa
 // (seqindex.c:265-276): sp unless the interval emptied before the last step.
+//
+// VERIFY (the index keeps SA, ISA and the text): once the interval is a single
+// row its remaining steps are decided by the text -- the row's suffix starts
+// at SA[sp], so the bases still to be prepended either equal the text before
+// that position (then every further interval is the single row ISA[pos - k])
+// or differ first at some base, where one ordinary step from the row reached
+// so far gives the empty interval loc_search stops with.  Same outputs, a
+// handful of reads instead of two rank queries per remaining base.
+template <bool VERIFY>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R, uint32_t m,
          uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow) {
@@ -81,27 +98,76 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   uint32_t sp = c == 0 ? C.c[0] : c == 1 ? C.c[1] : c == 2 ? C.c[2] : C.c[3];
   uint32_t ep = c == 0 ? C.c[1] : c == 1 ? C.c[2] : c == 2 ? C.c[3] : C.c[4];
   bool early = false;
+  const uint4 *sym = reinterpret_cast<const uint4 *>(v.sym);
   for (i = (int)m - 2; i >= 0; --i) {
     if ((i & 15) == 15) word = packed[(uint64_t)(i >> 4) * R + r];
     if (ep <= sp) {  // seqindex.c:299-301
       early = true;
       break;
     }
+    if (VERIFY && ep - sp == 1) break;
     c = (word >> (2 * (i & 15))) & 3u;
     // rank() first steps over the unstored $ row (seqindex.c:222-223)
     const uint32_t js = sp - (sp > v.endloc), je = ep - (ep > v.endloc);
     uint32_t rs, re;
     const uint32_t bs = div96(js, rs), be = div96(je, re);
-    const uint4 *col = reinterpret_cast<const uint4 *>(v.sym) + (uint64_t)c * v.nsym;
+    const uint4 *col = sym + (uint64_t)c * v.nsym;
     const uint4 blk_s = col[bs];
     uint4 blk_e = blk_s;
     if (be != bs) blk_e = col[be];  // narrow intervals share the block
     sp = sym_count(blk_s, rs);
     ep = sym_count(blk_e, re);
   }
+  if (VERIFY && !early && i >= 0 && ep - sp == 1) {
+    const uint32_t rem = (uint32_t)i + 1;  // read bases 0..i are still to be prepended
+    const uint32_t pos = v.sa[sp];
+    const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
+    // the highest read base j in [jmin, rem) that differs from text[pos - rem + j]
+    int jbad = -1;
+    for (int w = (int)((rem - 1) >> 4); w >= 0 && jbad < 0; --w) {
+      const uint32_t lo = jmin > 16u * w ? jmin - 16u * w : 0u;
+      if (lo >= 16) break;
+      const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
+      const uint32_t rw = packed[(uint64_t)w * R + r];
+      const uint32_t tw = text16(v.text2, (int64_t)pos - rem + 16 * w);
+      uint32_t d = rw ^ tw;
+      d = (d | (d >> 1)) & 0x55555555u;
+      const uint32_t keep = (hi == 16 ? ~0u : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
+      d &= keep;
+      if (d) jbad = 16 * w + (31 - __clz((int)d)) / 2;
+    }
+    if (jbad < 0 && jmin > 0) jbad = (int)jmin - 1;  // ran off the start of the text
+    if (jbad < 0) {
+      sp = v.isa[pos - rem];
+      ep = sp + 1;
+    } else {
+      const uint32_t k = rem - 1 - (uint32_t)jbad;  // bases that did match
+      const uint32_t row = k ? v.isa[pos - k] : sp;
+      c = (packed[(uint64_t)(jbad >> 4) * R + r] >> (2 * (jbad & 15))) & 3u;
+      const uint32_t js = row - (row > v.endloc), je = row + 1 - (row + 1 > v.endloc);
+      uint32_t rs, re;
+      const uint32_t bs = div96(js, rs), be = div96(je, re);
+      const uint4 *col = sym + (uint64_t)c * v.nsym;
+      const uint4 blk_s = col[bs];
+      uint4 blk_e = blk_s;
+      if (be != bs) blk_e = col[be];
+      sp = sym_count(blk_s, rs);
+      ep = sym_count(blk_e, re);
+      early = jbad > 0;  // a further base remained, so loc_search sees the empty interval and stops
+    }
+  }
   d_sp[r] = sp;
   d_ep[r] = ep;
   if (d_locrow) d_locrow[r] = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
+}
+
+// locate when the index keeps the whole suffix array: one lookup per row
+__global__ void k_locate_sa(IndexView v, const uint32_t *__restrict__ rows, uint64_t R,
+                            uint32_t *__restrict__ pos) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint32_t row = rows[r];
+  pos[r] = row > v.n ? 0xFFFFFFFFu : v.sa[row];
 }
 
 constexpr uint32_t kLocateBatch = 256;  // rows a wave takes from the queue at a time
@@ -241,8 +307,12 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
   BWT_CHECK_LAUNCH();
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
-  BWT_LAUNCH("fm_search", k_search, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
-             packed, R, m, d_sp, d_ep, d_locrow);
+  if (ix->d_sa)
+    BWT_LAUNCH("fm_search", k_search<true>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
+               packed, R, m, d_sp, d_ep, d_locrow);
+  else
+    BWT_LAUNCH("fm_search", k_search<false>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
+               packed, R, m, d_sp, d_ep, d_locrow);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
@@ -258,6 +328,12 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
                      bwtgpu_locate_workspace_bytes());
   if ((uintptr_t)d_ws & 7u) return set_error(kErrArg, "workspace must be 8-byte aligned");
   if (R == 0) return kOk;
+  if (ix->d_sa) {
+    BWT_LAUNCH("fm_locate", k_locate_sa, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows,
+               R, d_pos);
+    BWT_CHECK_LAUNCH();
+    return kOk;
+  }
   unsigned long long *head = reinterpret_cast<unsigned long long *>(d_ws);
   BWT_HIP(hipMemsetAsync(head, 0, 256, s));
   // enough waves to fill the chip (256 CUs x 8 waves/SIMD x 4 SIMDs), no more

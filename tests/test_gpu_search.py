@@ -146,3 +146,69 @@ def test_device_generators_match_host(oracle, gpu):
     r_o, o_o = oracle.gen_reads(host, n, R, m, synth.READS_SEED)
     np.testing.assert_array_equal(reads[: R * m].cpu().numpy().reshape(R, m), r_o)
     np.testing.assert_array_equal(gpu.to_numpy_u32(offs), o_o)
+
+
+def _mutated_reads(text_bases, n, R, m, seed):
+    """Reads cut from the text, then altered so that every branch of a search
+    is taken: exact copies, one substitution at a random base, reads hanging
+    over the start of the text, reads hanging over its end, random reads."""
+    rng = np.random.default_rng(seed)
+    reads = np.empty((R, m), np.uint8)
+    for r in range(R):
+        kind = r % 5
+        if kind == 3 and n >= 2:      # last bases are text[0:k], the bases in front are not text
+            k = int(rng.integers(1, min(m, n) + 1))
+            reads[r, : m - k] = rng.integers(0, 4, m - k)
+            reads[r, m - k:] = text_bases[:k]
+        elif kind == 4 or n < m:      # random, mostly absent
+            reads[r] = rng.integers(0, 4, m)
+        else:
+            j = int(rng.integers(0, n - m + 1))
+            reads[r] = text_bases[j: j + m]
+            if kind == 1:
+                q = int(rng.integers(0, m))
+                reads[r, q] = (reads[r, q] + 1 + int(rng.integers(0, 3))) & 3
+            elif kind == 2:           # copy that runs off the end of the text
+                k = int(rng.integers(1, m))
+                reads[r, :k] = text_bases[n - k:]
+                reads[r, k:] = rng.integers(0, 4, m - k)
+    return reads
+
+
+@pytest.mark.parametrize("n,R,m,kind", [(40, 600, 9, "random"), (777, 2000, 25, "random"),
+                                        (100003, 20000, 50, "random"), (1000000, 20000, 100, "random"),
+                                        (200000, 10000, 64, "mutated-repeat"), (50000, 5000, 33, "tandem")],
+                         ids=lambda v: str(v))
+def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R, m, kind):
+    """An index built on the device keeps SA, ISA and the text and finishes a
+    search from the text once one row is left; an index loaded from its stored
+    parts has only the rank blocks.  Both must give loc_search's interval
+    (seqindex.c:280-309) and locate's row (seqindex.c:258-277) for every read."""
+    if kind == "random":
+        text = oracle.gen_genome(n, synth.GENOME_SEED + n)
+    elif kind == "tandem":
+        text = oracle.gen_tandem(n, 7, 11)
+    else:
+        text = oracle.gen_tandem(n, 1000, 11, 50, 3)
+    bases = synth.unpack(text, n)
+    fo = oracle.make_fmi(text, n, oracle.sa_doubling(text, n) if kind != "random" else None)
+    full = gpu.build_index(text, n)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    assert full.device_bytes > lean.device_bytes + 8 * n
+    reads = _mutated_reads(bases, n, R, m, 1234 + n)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    d = torch.from_numpy(reads.reshape(-1)).cuda()
+    out = {}
+    for name, ix in (("full", full), ("lean", lean)):
+        sp, ep, lr = (gpu.to_numpy_u32(x) for x in ix.search(d, m, R, want_locrow=True))
+        np.testing.assert_array_equal(sp, sp_o, err_msg=name)
+        np.testing.assert_array_equal(ep, ep_o, err_msg=name)
+        pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))
+        out[name] = (lr, pos)
+    np.testing.assert_array_equal(out["full"][0], out["lean"][0])
+    np.testing.assert_array_equal(out["full"][1], out["lean"][1])
+    want = np.array([oracle.locate(fo, reads[r]) for r in range(min(R, 3000))], np.int64)
+    got = out["full"][1][: len(want)].astype(np.int64)
+    got[got == 0xFFFFFFFF] = -1
+    np.testing.assert_array_equal(got, want)
+    assert (ep_o > sp_o).sum() > R // 8 and (ep_o <= sp_o).sum() > R // 8
