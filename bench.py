@@ -30,14 +30,26 @@ from bwt_amd import synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def search_bytes_per_read(m, locate_steps=None):
-    """Algorithmic HBM bytes per read: m/4 packed pattern + one 32-byte index
-    block per rank query (2 per backward-search step) + 8 bytes of (sp, ep);
-    with locate, one block per LF step + 4 bytes of position."""
+def rank_only_bytes_per_read(m, locate_steps=None):
+    """Algorithmic HBM bytes per read of a search made of rank queries alone:
+    m/4 packed pattern + one 32-byte index block per rank query (2 per
+    backward-search step) + 8 bytes of (sp, ep); with locate, one block per
+    LF step + 4 bytes of position."""
     b = m / 4 + 32.0 * 2 * (m - 1) + 8
     if locate_steps is not None:
         b += 32.0 * locate_steps + 4
     return b
+
+
+def measured_traffic(workload_key):
+    """HBM bytes per fm_search launch from the committed PMC passes of this
+    workload (profiles/pmc_fm_search.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_fm_search.json")) as f:
+            rec = json.load(f)
+        return rec.get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(args, d_text, n, d_reads, R, m, gpu_sp, gpu_ep):
@@ -156,13 +168,17 @@ def main():
         elapsed = float(t.item())
 
     # ---- locate (unc_sa) of every read's first row: reported beside, not in value ----
-    G.timing_reset()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    pos, lf_steps = ix.locate_rows(lr, count_steps=True)
-    torch.cuda.synchronize()
-    locate_s = time.perf_counter() - t0
-    locate_kernels = G.timing_report()
+    def time_locate():
+        G.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pos, steps = ix.locate_rows(lr, count_steps=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        launches, ms = G.timing_report().get("fm_locate", (0, 0.0))
+        return pos, steps, dt, ms / max(launches, 1)
+
+    pos, _, locate_s, loc_ms = time_locate()
     located = int((pos != -1).sum().item())
 
     if rank != 0:
@@ -172,9 +188,33 @@ def main():
 
     n_launch, ms_total = search_kernels.get("fm_search", (0, 0.0))
     k_ms = ms_total / max(n_launch, 1)
-    bpr = search_bytes_per_read(m)
+    # bytes the search loads and stores, counted by the kernel itself on this batch
+    G.timing_enable(False)
+    loads, sp_c, ep_c = ix.search_loads(d_reads, m, R)
+    counted_ok = bool(torch.equal(sp_c, sp) and torch.equal(ep_c, ep))
+    bpr = loads["bytes"] / R + 12.0  # + sp, ep, locate row written
     achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
-    loc_launch, loc_ms = locate_kernels.get("fm_locate", (0, 0.0))
+    index_bytes = ix.device_bytes
+
+    # ---- the same batch on rank blocks alone (what an index loaded from a file has) ----
+    ix.compact()
+    sp2, ep2, lr2 = (torch.empty_like(sp) for _ in range(3))
+    ix.search(d_reads, m, R, want_locrow=True, out=(sp2, ep2, lr2))
+    G.timing_enable(True)
+    G.timing_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ix.search(d_reads, m, R, want_locrow=True, out=(sp2, ep2, lr2))
+    torch.cuda.synchronize()
+    ro_elapsed = time.perf_counter() - t0
+    ro_launch, ro_total = G.timing_report().get("fm_search", (0, 0.0))
+    ro_ms = ro_total / max(ro_launch, 1)
+    ro_same = bool(torch.equal(sp2, sp) and torch.equal(ep2, ep) and torch.equal(lr2, lr))
+    pos2, lf_steps, ro_locate_s, ro_loc_ms = time_locate()
+    ro_same = ro_same and bool(torch.equal(pos2, pos))
+    ro_bpr = rank_only_bytes_per_read(m)
+    ro_achieved = ro_bpr * R / (ro_ms * 1e-3) / 1e9 if ro_ms else 0.0
     loc_bytes = 32.0 * lf_steps + 8.0 * located
     sa_ms = sum(v[1] / max(args.build_reps, 1) for k, v in build_kernels.items()
                 if k.startswith(("sa_", "dbl_", "rs_", "scan_")))
@@ -203,15 +243,33 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic(f"{n}bp_{R}x{m}"),
             "bytes_per_read": bpr,
+            "loads": loads,
+            "counting_pass_matches": counted_ok,
             "kernel_ms": k_ms,
+            "what": "bytes the kernel loads and stores, counted per batch by its counting build "
+                    "(16 B rank blocks, 8 B text windows, 4 B SA/ISA entries, packed pattern words, 12 B out)",
+        },
+        "rank_only": {
+            "what": "same batch after dropping SA/ISA/text from the index: every step is two rank queries",
+            "value": R * args.steps / ro_elapsed,
+            "unit": "reads/s",
+            "kernel_ms": ro_ms,
+            "same_output": ro_same,
+            "roofline": {"bound": "hbm", "bytes_per_read": ro_bpr, "achieved": ro_achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ro_achieved / HBM_PEAK_GBS},
+            "locate": {"value": R / ro_locate_s, "unit": "rows/s",
+                       "lf_steps_per_row": lf_steps / max(located, 1), "kernel_ms": ro_loc_ms,
+                       "achieved_gbs": loc_bytes / (ro_loc_ms * 1e-3) / 1e9 if ro_loc_ms else 0.0},
+            "index_bytes": ix.device_bytes,
         },
         "sa_build": {
             "value": n / build_s / 1e6,
             "unit": "Mbp/s",
             "wall_ms": build_s * 1e3,
-            "what": "make_fmi on device: text in HBM -> SA, BWT, sampled SA, rank blocks, C[] (SA stays in HBM)",
+            "what": "make_fmi on device: text in HBM -> SA, BWT, sampled SA, rank blocks, C[], "
+                    "plus inverse SA and word-packed text kept for search",
             "sa_kernels_ms": sa_ms,
             "roofline": {
                 "bound": "hbm", "bytes_per_bp": 5.625,
@@ -225,12 +283,12 @@ def main():
         "locate": {
             "value": R / locate_s,
             "unit": "rows/s",
-            "lf_steps_per_row": lf_steps / max(located, 1),
-            "kernel_ms": loc_ms / max(loc_launch, 1),
-            "achieved_gbs": loc_bytes / (loc_ms * 1e-3) / 1e9 if loc_ms else 0.0,
+            "what": "one SA entry per row (the index keeps the whole suffix array)",
+            "kernel_ms": loc_ms,
+            "achieved_gbs": 12.0 * located / (loc_ms * 1e-3) / 1e9 if loc_ms else 0.0,
         },
         "search_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(search_kernels.items())},
-        "index_bytes": ix.device_bytes,
+        "index_bytes": index_bytes,
     }
     if not args.no_cpu and world == 1:
         gs = G.to_numpy_u32(sp[: args.cpu_reads])

@@ -56,6 +56,8 @@ SIGNATURES = {
     "bwtgpu_lf_host": (C.c_int, [vp, vp, u64, vp]),
     "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
     "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
+    "bwtgpu_index_compact": (C.c_int, [vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),
     "bwtgpu_locate_rows": (C.c_int, [vp, vp, u64, vp, vp, vp, sz, vp]),
     "bwtgpu_gen_genome": (C.c_int, [vp, u64, u64, vp]),

@@ -441,6 +441,17 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
          (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0);
 }
 
+int bwtgpu_index_compact(bwtgpu_index *ix) {
+  if (!ix) return set_error(kErrArg, "null index");
+  BWT_HIP(hipSetDevice(ix->device));
+  BWT_HIP(hipDeviceSynchronize());  // searches in flight may still read the arrays
+  if (ix->d_sa) (void)hipFree(ix->d_sa);
+  if (ix->d_isa) (void)hipFree(ix->d_isa);
+  if (ix->d_text2) (void)hipFree(ix->d_text2);
+  ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+  return kOk;
+}
+
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {
   if (!ix) return set_error(kErrArg, "null index");
   BWT_HIP(hipSetDevice(ix->device));

@@ -86,12 +86,18 @@ __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, i
 // or differ first at some base, where one ordinary step from the row reached
 // so far gives the empty interval loc_search stops with.  Same outputs, a
 // handful of reads instead of two rank queries per remaining base.
-template <bool VERIFY>
+//
+// COUNT adds up what the batch loaded (see bwtgpu_search_profile): counters[0]
+// 16-byte rank blocks, [1] 8-byte text windows, [2] 4-byte SA/ISA entries,
+// [3] 4-byte pattern words.
+template <bool VERIFY, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R, uint32_t m,
-         uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow) {
+         uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
+         unsigned long long *__restrict__ counters) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
+  uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1;
+  if (r < R) {
   int i = (int)m - 1;
   uint32_t word = packed[(uint64_t)(i >> 4) * R + r];
   uint32_t c = (word >> (2 * (i & 15))) & 3u;
@@ -100,7 +106,10 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   bool early = false;
   const uint4 *sym = reinterpret_cast<const uint4 *>(v.sym);
   for (i = (int)m - 2; i >= 0; --i) {
-    if ((i & 15) == 15) word = packed[(uint64_t)(i >> 4) * R + r];
+    if ((i & 15) == 15) {
+      word = packed[(uint64_t)(i >> 4) * R + r];
+      if (COUNT) ++n_pat;
+    }
     if (ep <= sp) {  // seqindex.c:299-301
       early = true;
       break;
@@ -115,12 +124,14 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
     const uint4 blk_s = col[bs];
     uint4 blk_e = blk_s;
     if (be != bs) blk_e = col[be];  // narrow intervals share the block
+    if (COUNT) n_blk += 1 + (be != bs);
     sp = sym_count(blk_s, rs);
     ep = sym_count(blk_e, re);
   }
   if (VERIFY && !early && i >= 0 && ep - sp == 1) {
     const uint32_t rem = (uint32_t)i + 1;  // read bases 0..i are still to be prepended
     const uint32_t pos = v.sa[sp];
+    if (COUNT) n_ent += 2;  // this and the one ISA entry read below
     const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
     // the highest read base j in [jmin, rem) that differs from text[pos - rem + j]
     int jbad = -1;
@@ -130,6 +141,10 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
       const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
       const uint32_t rw = packed[(uint64_t)w * R + r];
       const uint32_t tw = text16(v.text2, (int64_t)pos - rem + 16 * w);
+      if (COUNT) {
+        ++n_txt;
+        ++n_pat;
+      }
       uint32_t d = rw ^ tw;
       d = (d | (d >> 1)) & 0x55555555u;
       const uint32_t keep = (hi == 16 ? ~0u : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
@@ -151,6 +166,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
       const uint4 blk_s = col[bs];
       uint4 blk_e = blk_s;
       if (be != bs) blk_e = col[be];
+      if (COUNT) n_blk += 1 + (be != bs);
       sp = sym_count(blk_s, rs);
       ep = sym_count(blk_e, re);
       early = jbad > 0;  // a further base remained, so loc_search sees the empty interval and stops
@@ -159,6 +175,15 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   d_sp[r] = sp;
   d_ep[r] = ep;
   if (d_locrow) d_locrow[r] = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
+  }
+  if (COUNT) {
+    if (r >= R) n_pat = 0;
+    unsigned long long t[4] = {n_blk, n_txt, n_ent, n_pat};
+    for (int q = 0; q < 4; ++q) {
+      for (int off = 32; off; off >>= 1) t[q] += __shfl_down(t[q], off, 64);
+      if ((threadIdx.x & 63u) == 0 && t[q]) atomicAdd(counters + q, t[q]);
+    }
+  }
 }
 
 // locate when the index keeps the whole suffix array: one lookup per row
@@ -284,10 +309,9 @@ size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m) {
   return align_up((size_t)((m + 15) / 16) * R * sizeof(uint32_t), 256) + 256;
 }
 
-int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
-                  uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
-                  size_t ws_bytes, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+                       uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
+                       size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
   if (!ix || !d_pats || !d_sp || !d_ep || !d_ws) return set_error(kErrArg, "null argument");
   if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
   if (R == 0) return kOk;
@@ -307,13 +331,51 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
   BWT_CHECK_LAUNCH();
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
-  if (ix->d_sa)
-    BWT_LAUNCH("fm_search", k_search<true>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
-               packed, R, m, d_sp, d_ep, d_locrow);
-  else
-    BWT_LAUNCH("fm_search", k_search<false>, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), C,
-               packed, R, m, d_sp, d_ep, d_locrow);
+  const dim3 grid((unsigned)div_up(R, 256)), block(256);
+  const IndexView v = view_of(ix);
+  if (d_counters) {
+    if (ix->d_sa)
+      BWT_LAUNCH("fm_search_counting", (k_search<true, true>), grid, block, 0, s, v, C, packed, R, m, d_sp,
+                 d_ep, d_locrow, d_counters);
+    else
+      BWT_LAUNCH("fm_search_counting", (k_search<false, true>), grid, block, 0, s, v, C, packed, R, m, d_sp,
+                 d_ep, d_locrow, d_counters);
+  } else if (ix->d_sa) {
+    BWT_LAUNCH("fm_search", (k_search<true, false>), grid, block, 0, s, v, C, packed, R, m, d_sp, d_ep,
+               d_locrow, d_counters);
+  } else {
+    BWT_LAUNCH("fm_search", (k_search<false, false>), grid, block, 0, s, v, C, packed, R, m, d_sp, d_ep,
+               d_locrow, d_counters);
+  }
   BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
+int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+                  uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
+                  size_t ws_bytes, void *stream) {
+  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_ws, ws_bytes, nullptr,
+                     (hipStream_t)stream);
+}
+
+int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+                          uint64_t R, uint32_t *d_sp, uint32_t *d_ep, void *d_ws, size_t ws_bytes,
+                          uint64_t loads[4], void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!loads) return set_error(kErrArg, "null argument");
+  // the counters take the first 256 bytes of the workspace, the packed reads the rest
+  if (ws_bytes < bwtgpu_search_workspace_bytes(R, m) + 256)
+    return set_error(kErrWorkspace, "search profile workspace %zu < %zu bytes", ws_bytes,
+                     bwtgpu_search_workspace_bytes(R, m) + 256);
+  if (!d_ws || ((uintptr_t)d_ws & 255u)) return set_error(kErrArg, "workspace must be 256-byte aligned");
+  unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_ws);
+  BWT_HIP(hipMemsetAsync(ctr, 0, 256, s));
+  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
+                      s));
+  unsigned long long h[4];
+  BWT_HIP(hipMemcpyAsync(h, ctr, sizeof h, hipMemcpyDeviceToHost, s));
+  BWT_HIP(hipStreamSynchronize(s));
+  for (int q = 0; q < 4; ++q) loads[q] = h[q];
   return kOk;
 }
 

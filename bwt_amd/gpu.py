@@ -132,6 +132,25 @@ class GpuIndex:
                                 _ptr(ws), ws.numel(), _stream()))
         return (sp, ep, lr) if want_locrow else (sp, ep)
 
+    def search_loads(self, d_pats, m, R, stride=None):
+        """Loads one search of the batch makes: dict of counts (see
+        bwtgpu_search_profile) and the bytes they add up to."""
+        lib = _lib.load()
+        stride = m if stride is None else stride
+        sp = torch.empty(R, dtype=torch.int32, device="cuda")
+        ep = torch.empty(R, dtype=torch.int32, device="cuda")
+        ws = torch.empty(int(lib.bwtgpu_search_workspace_bytes(R, m)) + 256, dtype=torch.uint8, device="cuda")
+        loads = (C.c_uint64 * 4)()
+        check(lib.bwtgpu_search_profile(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(ws),
+                                        ws.numel(), loads, _stream()))
+        blk, txt, ent, pat = (int(x) for x in loads)
+        return {"rank_blocks_16B": blk, "text_windows_8B": txt, "sa_isa_entries_4B": ent,
+                "pattern_words_4B": pat, "bytes": 16 * blk + 8 * txt + 4 * ent + 4 * pat}, sp, ep
+
+    def compact(self):
+        """Drop the kept suffix array, its inverse and the text (see bwtgpu_index_compact)."""
+        check(_lib.load().bwtgpu_index_compact(self.h))
+
     def locate_rows(self, d_rows, count_steps=False, out=None):
         lib = _lib.load()
         R = d_rows.numel()

@@ -212,3 +212,27 @@ def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R
     got[got == 0xFFFFFFFF] = -1
     np.testing.assert_array_equal(got, want)
     assert (ep_o > sp_o).sum() > R // 8 and (ep_o <= sp_o).sum() > R // 8
+
+
+def test_compact_drops_the_kept_arrays_and_counting_search_agrees(oracle, gpu):
+    n, R, m = 300000, 8000, 40
+    text = oracle.gen_genome(n, 77)
+    fo = oracle.make_fmi(text, n)
+    ix = gpu.build_index(text, n)
+    reads = _mutated_reads(synth.unpack(text, n), n, R, m, 5)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    d = torch.from_numpy(reads.reshape(-1)).cuda()
+    big = ix.device_bytes
+    loads_full, sp, ep = ix.search_loads(d, m, R)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+    ix.compact()
+    assert ix.device_bytes < big - 8 * n
+    loads_lean, sp, ep = ix.search_loads(d, m, R)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
+    assert loads_lean["text_windows_8B"] == 0 and loads_lean["sa_isa_entries_4B"] == 0
+    assert loads_full["text_windows_8B"] > 0
+    assert loads_full["rank_blocks_16B"] < loads_lean["rank_blocks_16B"] <= 2 * (m - 1) * R
+    rows = torch.arange(0, n + 1, 7, dtype=torch.int64, device="cuda").to(torch.int32)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n)[::7])
