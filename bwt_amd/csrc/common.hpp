@@ -130,6 +130,12 @@ struct bwtgpu_index {
   uint32_t *d_sa = nullptr;     // n+1 rows
   uint32_t *d_isa = nullptr;    // n+1 positions -> row
   uint32_t *d_text2 = nullptr;  // [0] guard, [1 + w] = bases 16w..16w+15, base k at bits 2k
+  // Optional: the SA interval of every string of kmer_k bases, i.e. the state of
+  // a backward search after its first kmer_k steps, indexed by the string read
+  // as a base-4 number (first base most significant); (0, 0) where the string
+  // does not occur.  A search of a read of at least kmer_k bases starts there.
+  uint2 *d_kmer = nullptr;
+  uint32_t kmer_k = 0;
   int device = 0;
 };
 
@@ -142,6 +148,7 @@ inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // index.hip
 int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
+int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known
 int index_alloc(bwtgpu_index **out, uint32_t n);
 
 // sa_build.hip

@@ -221,6 +221,7 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   }
   if (rc == kOk) rc = index_finish_from_planes(ix, s);  // synchronises the stream
   if (rc == kOk && ix->endloc > n) rc = set_error(kErrInternal, "no suffix-array row holds suffix 0");
+  if (rc == kOk) rc = index_build_kmer_table(ix, s);
   cleanup();
   if (rc != kOk) {
     bwtgpu_index_free(ix);

@@ -1,6 +1,8 @@
 // FM-index object in HBM: rank blocks from a packed BWT (the rebuild that
 // read_index does on the host, fileio.c:62-63 -> seq_index, seqindex.c:23-87),
 // export of the stored parts, and the reference-layout rank rows.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "fm_device.hpp"
 
@@ -307,6 +309,76 @@ __global__ void k_thin_samples(const uint32_t *__restrict__ dense, uint64_t nsto
   if (i < nstored) stored[i] = dense[i << (kFileSampleShift - kDevSampleShift)];
 }
 
+// One level of the k-mer interval table: the interval of string c.x (x of j
+// bases) is one backward-search step (seqindex.c:292-306) from the interval of
+// x.  Strings are numbered with their first base most significant, so
+// neighbouring threads extend neighbouring intervals with the same base and the
+// rank queries of a wave fall on neighbouring blocks.
+__global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
+                             uint32_t j) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (1ull << (2 * (j + 1)))) return;
+  const uint32_t c = (uint32_t)(q >> (2 * j));
+  const uint2 p = src[q & ((1ull << (2 * j)) - 1ull)];
+  uint2 o = make_uint2(0u, 0u);
+  if (p.y > p.x) {
+    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+    const uint32_t sp = occ_c(v, c, nlo, nhi, p.x), ep = occ_c(v, c, nlo, nhi, p.y);
+    if (ep > sp) o = make_uint2(sp, ep);
+  }
+  dst[q] = o;
+}
+
+// Table size: about one entry per base (the interval of a string of
+// floor(log4 n) bases holds a few rows), at most 4^13 entries (512 MiB);
+// BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT means none.
+static uint32_t kmer_table_k(uint32_t n) {
+  if (getenv("BWT_MI355X_COMPACT")) return 0;
+  if (const char *e = getenv("BWT_MI355X_KMER")) {
+    const long k = strtol(e, nullptr, 10);
+    return k < 2 ? 0u : (k > 14 ? 14u : (uint32_t)k);
+  }
+  uint32_t k = 0;
+  while (k < 13 && (1ull << (2 * (k + 1))) <= (uint64_t)n) ++k;
+  return k < 6 ? 0u : k;
+}
+
+int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
+  const uint32_t K = kmer_table_k(ix->n);
+  if (K == 0) return kOk;
+  const uint64_t entries = 1ull << (2 * K);
+  uint2 *tab = nullptr, *tmp = nullptr;
+  if (hipMalloc(&tab, entries * sizeof(uint2)) != hipSuccess ||
+      hipMalloc(&tmp, (entries / 4) * sizeof(uint2)) != hipSuccess) {
+    (void)hipGetLastError();  // short of memory: searches start from the first base instead
+    if (tab) (void)hipFree(tab);
+    return kOk;
+  }
+  // level j lives in tab when K - j is even, in tmp otherwise, so level K ends in tab
+  auto buf = [&](uint32_t j) { return ((K - j) & 1u) ? tmp : tab; };
+  uint2 first[4];
+  for (uint32_t c = 0; c < 4; ++c)
+    first[c] = ix->C[c + 1] > ix->C[c] ? make_uint2(ix->C[c], ix->C[c + 1]) : make_uint2(0u, 0u);
+  hipError_t e = hipMemcpyAsync(buf(1), first, sizeof first, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);  // first[] leaves the stack
+  const IndexView v = view_of(ix);
+  for (uint32_t j = 1; j < K && e == hipSuccess; ++j) {
+    const uint64_t out = 1ull << (2 * (j + 1));
+    BWT_LAUNCH("kmer_level", k_kmer_level, dim3((unsigned)div_up(out, 256)), dim3(256), 0, s, v, buf(j),
+               buf(j + 1), j);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(tmp);
+  if (e != hipSuccess) {
+    (void)hipFree(tab);
+    return set_error(kErrHip, "k-mer table build: %s", hipGetErrorString(e));
+  }
+  ix->d_kmer = tab;
+  ix->kmer_k = K;
+  return kOk;
+}
+
 int index_alloc(bwtgpu_index **out, uint32_t n) {
   if (n == 0 || n > 0xFFFFFFF0u)
     return set_error(kErrArg, "text length %u out of range", n);
@@ -366,6 +438,7 @@ void bwtgpu_index_free(bwtgpu_index *ix) {
   if (ix->d_sa) (void)hipFree(ix->d_sa);
   if (ix->d_isa) (void)hipFree(ix->d_isa);
   if (ix->d_text2) (void)hipFree(ix->d_text2);
+  if (ix->d_kmer) (void)hipFree(ix->d_kmer);
   delete ix;
 }
 
@@ -410,6 +483,7 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
                        reinterpret_cast<const uint4 *>(d_bwt), ix->d_blocks, nb, n);
   }
   int rc = index_finish_from_planes(ix, s);
+  if (rc == kOk) rc = index_build_kmer_table(ix, s);
   if (rc == kOk && h_idxs) {
     ScopedKernelTimer t("densify_samples", s);
     hipLaunchKernelGGL(k_densify_samples, dim3((unsigned)div_up(ndense, 256)), dim3(256), 0, s,
@@ -438,7 +512,8 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
-         (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0);
+         (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
+         (ix->d_kmer ? sizeof(uint2) << (2 * ix->kmer_k) : 0);
 }
 
 int bwtgpu_index_compact(bwtgpu_index *ix) {
@@ -448,7 +523,10 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   if (ix->d_sa) (void)hipFree(ix->d_sa);
   if (ix->d_isa) (void)hipFree(ix->d_isa);
   if (ix->d_text2) (void)hipFree(ix->d_text2);
+  if (ix->d_kmer) (void)hipFree(ix->d_kmer);
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+  ix->d_kmer = nullptr;
+  ix->kmer_k = 0;
   return kOk;
 }
 

@@ -89,23 +89,47 @@ __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, i
 //
 // COUNT adds up what the batch loaded (see bwtgpu_search_profile): counters[0]
 // 16-byte rank blocks, [1] 8-byte text windows, [2] 4-byte SA/ISA entries,
-// [3] 4-byte pattern words.
+// [3] 4-byte pattern words, [4] 8-byte k-mer table entries.
 template <bool VERIFY, bool COUNT>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R, uint32_t m,
          uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
          unsigned long long *__restrict__ counters) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1;
+  uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1, n_kmr = 0;
   if (r < R) {
-  int i = (int)m - 1;
-  uint32_t word = packed[(uint64_t)(i >> 4) * R + r];
-  uint32_t c = (word >> (2 * (i & 15))) & 3u;
-  uint32_t sp = c == 0 ? C.c[0] : c == 1 ? C.c[1] : c == 2 ? C.c[2] : C.c[3];
-  uint32_t ep = c == 0 ? C.c[1] : c == 1 ? C.c[2] : c == 2 ? C.c[3] : C.c[4];
+  int i = -2;
+  uint32_t word = 0, c, sp = 0, ep = 0;
+  const uint32_t K = v.kmer_k;
+  if (K && m >= K) {
+    // the last K bases as a base-4 number, first base most significant
+    const uint32_t a = m - K, wa = a >> 4;
+    const uint32_t w0 = packed[(uint64_t)wa * R + r];
+    const uint32_t w1 = wa < ((m - 1) >> 4) ? packed[(uint64_t)(wa + 1) * R + r] : 0u;
+    if (COUNT) n_pat += wa < ((m - 1) >> 4);
+    uint32_t x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (a & 15u)));  // base a in the low bits
+    x = __brev(x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);  // base a in the top bits
+    const uint2 e = v.kmer[x >> (32 - 2 * K)];
+    if (COUNT) ++n_kmr;
+    if (e.y > e.x) {
+      sp = e.x;
+      ep = e.y;
+      word = w0;
+      i = (int)a - 1;
+    }
+  }
+  if (i == -2) {  // no table, a short read, or a string the text does not hold: step by step
+    i = (int)m - 1;
+    word = packed[(uint64_t)(i >> 4) * R + r];
+    c = (word >> (2 * (i & 15))) & 3u;
+    sp = c == 0 ? C.c[0] : c == 1 ? C.c[1] : c == 2 ? C.c[2] : C.c[3];
+    ep = c == 0 ? C.c[1] : c == 1 ? C.c[2] : c == 2 ? C.c[3] : C.c[4];
+    i = (int)m - 2;
+  }
   bool early = false;
   const uint4 *sym = reinterpret_cast<const uint4 *>(v.sym);
-  for (i = (int)m - 2; i >= 0; --i) {
+  for (; i >= 0; --i) {
     if ((i & 15) == 15) {
       word = packed[(uint64_t)(i >> 4) * R + r];
       if (COUNT) ++n_pat;
@@ -178,8 +202,8 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   }
   if (COUNT) {
     if (r >= R) n_pat = 0;
-    unsigned long long t[4] = {n_blk, n_txt, n_ent, n_pat};
-    for (int q = 0; q < 4; ++q) {
+    unsigned long long t[5] = {n_blk, n_txt, n_ent, n_pat, n_kmr};
+    for (int q = 0; q < 5; ++q) {
       for (int off = 32; off; off >>= 1) t[q] += __shfl_down(t[q], off, 64);
       if ((threadIdx.x & 63u) == 0 && t[q]) atomicAdd(counters + q, t[q]);
     }
@@ -360,7 +384,7 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
 
 int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                           uint64_t R, uint32_t *d_sp, uint32_t *d_ep, void *d_ws, size_t ws_bytes,
-                          uint64_t loads[4], void *stream) {
+                          uint64_t loads[5], void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!loads) return set_error(kErrArg, "null argument");
   // the counters take the first 256 bytes of the workspace, the packed reads the rest
@@ -372,10 +396,10 @@ int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_
   BWT_HIP(hipMemsetAsync(ctr, 0, 256, s));
   BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
                       s));
-  unsigned long long h[4];
+  unsigned long long h[5];
   BWT_HIP(hipMemcpyAsync(h, ctr, sizeof h, hipMemcpyDeviceToHost, s));
   BWT_HIP(hipStreamSynchronize(s));
-  for (int q = 0; q < 4; ++q) loads[q] = h[q];
+  for (int q = 0; q < 5; ++q) loads[q] = h[q];
   return kOk;
 }
 

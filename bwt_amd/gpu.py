@@ -140,12 +140,13 @@ class GpuIndex:
         sp = torch.empty(R, dtype=torch.int32, device="cuda")
         ep = torch.empty(R, dtype=torch.int32, device="cuda")
         ws = torch.empty(int(lib.bwtgpu_search_workspace_bytes(R, m)) + 256, dtype=torch.uint8, device="cuda")
-        loads = (C.c_uint64 * 4)()
+        loads = (C.c_uint64 * 5)()
         check(lib.bwtgpu_search_profile(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(ws),
                                         ws.numel(), loads, _stream()))
-        blk, txt, ent, pat = (int(x) for x in loads)
+        blk, txt, ent, pat, kmr = (int(x) for x in loads)
         return {"rank_blocks_16B": blk, "text_windows_8B": txt, "sa_isa_entries_4B": ent,
-                "pattern_words_4B": pat, "bytes": 16 * blk + 8 * txt + 4 * ent + 4 * pat}, sp, ep
+                "pattern_words_4B": pat, "kmer_entries_8B": kmr,
+                "bytes": 16 * blk + 8 * txt + 4 * ent + 4 * pat + 8 * kmr}, sp, ep
 
     def compact(self):
         """Drop the kept suffix array, its inverse and the text (see bwtgpu_index_compact)."""

@@ -93,10 +93,12 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
 /* An index built on the device keeps, beside what make_fmi (seqindex.c:161-189)
  * produces, the whole suffix array, its inverse and the text (8.25 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
- * results are the same either way.  This call frees those three arrays and
- * leaves the rank blocks and the sampled suffix array, as an index loaded from
- * a file has them.  Setting BWT_MI355X_COMPACT in the environment makes every
- * build do so.  No counterpart in the reference. */
+ * every index also holds a table of the SA intervals of all strings of k bases
+ * (k = floor(log4 n), at most 13; BWT_MI355X_KMER=<k> overrides), where
+ * searches of longer reads start.  Results are the same with or without them.
+ * This call frees all four and leaves the rank blocks and the sampled suffix
+ * array.  Setting BWT_MI355X_COMPACT in the environment makes every build and
+ * load do so.  No counterpart in the reference. */
 int bwtgpu_index_compact(bwtgpu_index *ix);
 
 /* ---- backward search (HP2) ---- */
@@ -117,13 +119,14 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                   uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
 /* bwtgpu_search, and the number of loads the batch made: loads[0] 16-byte rank
  * blocks, loads[1] 8-byte text windows, loads[2] 4-byte SA/ISA entries,
- * loads[3] 4-byte packed pattern words.  For measurement (bytes a search
+ * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table entries.
+ * For measurement (bytes a search
  * needs); slower than bwtgpu_search and synchronises the stream.  Workspace:
  * bwtgpu_search_workspace_bytes(R, m) + 256 bytes.  No counterpart in the
  * reference. */
 int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                           uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
-                          void *d_ws, size_t ws_bytes, uint64_t loads[4], void *stream);
+                          void *d_ws, size_t ws_bytes, uint64_t loads[5], void *stream);
 /* Replaces the host loop over unc_sa (seqindex.c:244-255): d_pos[r] =
  * SA[d_rows[r]]; rows equal to 0xFFFFFFFF, or beyond n, give 0xFFFFFFFF.
  * If d_steps is not NULL the total number of LF steps taken is ADDED to it

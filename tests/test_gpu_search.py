@@ -168,7 +168,7 @@ def _mutated_reads(text_bases, n, R, m, seed):
             if kind == 1:
                 q = int(rng.integers(0, m))
                 reads[r, q] = (reads[r, q] + 1 + int(rng.integers(0, 3))) & 3
-            elif kind == 2:           # copy that runs off the end of the text
+            elif kind == 2 and m >= 2:  # copy that runs off the end of the text
                 k = int(rng.integers(1, m))
                 reads[r, :k] = text_bases[n - k:]
                 reads[r, k:] = rng.integers(0, 4, m - k)
@@ -236,3 +236,33 @@ def test_compact_drops_the_kept_arrays_and_counting_search_agrees(oracle, gpu):
     assert loads_full["rank_blocks_16B"] < loads_lean["rank_blocks_16B"] <= 2 * (m - 1) * R
     rows = torch.arange(0, n + 1, 7, dtype=torch.int64, device="cuda").to(torch.int32)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n)[::7])
+
+
+@pytest.mark.parametrize("k", [0, 2, 5, 9, 11])
+def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
+    """Searches start from the table entry of the read's last k bases; reads
+    shorter than k, reads of exactly k bases and absent strings included."""
+    n = 300000
+    text = oracle.gen_genome(n, 4242)
+    fo = oracle.make_fmi(text, n)
+    monkeypatch.setenv("BWT_MI355X_KMER", str(k))
+    full = gpu.build_index(text, n)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    monkeypatch.delenv("BWT_MI355X_KMER")
+    bases = synth.unpack(text, n)
+    for m in (1, 4, 8, 9, 10, 11, 12, 16, 17, 23, 32, 33, 70):
+        R = 3000
+        reads = _mutated_reads(bases, n, R, m, 100 + m)
+        sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+        d = torch.from_numpy(reads.reshape(-1)).cuda()
+        for name, ix in (("full", full), ("lean", lean)):
+            sp, ep, lr = (gpu.to_numpy_u32(x) for x in ix.search(d, m, R, want_locrow=True))
+            np.testing.assert_array_equal(sp, sp_o, err_msg=f"{name} m={m}")
+            np.testing.assert_array_equal(ep, ep_o, err_msg=f"{name} m={m}")
+            want = np.array([oracle.locate(fo, reads[r]) for r in range(300)], np.int64)
+            pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))[:300]
+            got = pos.astype(np.int64)
+            got[got == 0xFFFFFFFF] = -1
+            np.testing.assert_array_equal(got, want, err_msg=f"{name} m={m}")
+    loads, _, _ = full.search_loads(torch.from_numpy(reads.reshape(-1)).cuda(), 70, 3000)
+    assert loads["kmer_entries_8B"] == (3000 if k >= 2 else 0)
