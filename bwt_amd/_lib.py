@@ -56,6 +56,9 @@ SIGNATURES = {
     "bwtgpu_lf_host": (C.c_int, [vp, vp, u64, vp]),
     "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
     "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_sa_bucket_counts": (C.c_int, [vp, u32, vp, vp]),
+    "bwtgpu_sa_build_range": (C.c_int, [vp, u32, u32, u32, vp, vp, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_index_build_from_sa": (vp, [vp, u32, vp, vp, u32, vp]),
     "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
     "bwtgpu_index_compact": (C.c_int, [vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),
@@ -88,7 +91,9 @@ def load():
 
 def check(rc):
     if rc != 0:
-        raise BwtGpuError(f"libbwt_mi355x error {rc}: {load().bwtgpu_last_error().decode()}")
+        err = BwtGpuError(f"libbwt_mi355x error {rc}: {load().bwtgpu_last_error().decode()}")
+        err.code = rc
+        raise err
 
 
 def last_error():

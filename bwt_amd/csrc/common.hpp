@@ -22,6 +22,7 @@ enum : int {
   kErrWorkspace = -3, // workspace too small
   kErrDevice = -4,    // no usable gfx950 device
   kErrInternal = -5,  // invariant violated on device (reported, never ignored)
+  kErrNeedsWholeText = -6,  // a sharded suffix-array build met ties only a whole-text build orders
 };
 
 int set_error(int code, const char *fmt, ...);
@@ -160,6 +161,17 @@ struct SaExtras {
   const uint32_t *endloc = nullptr;
 };
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
+                  size_t ws_bytes, hipStream_t s, SaExtras *extras);
+// One shard of a build: the suffixes whose first four bases, read as a number
+// with the first base most significant, lie in [dlo, dhi).
+struct SaRange {
+  uint32_t dlo = 0, dhi = 256;  // in
+  uint64_t capacity = 0;        // in: rows d_sa has room for
+  uint64_t row_begin = 0;       // out: suffix-array row of the shard's first row
+  uint64_t rows = 0;            // out
+  uint32_t endloc = 0;          // out: row of suffix 0 if the shard holds it, else 0
+};
+int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *range, void *d_ws,
                   size_t ws_bytes, hipStream_t s, SaExtras *extras);
 
 }  // namespace bwtgpu

@@ -162,73 +162,103 @@ static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
   return kOk;
 }
 
+// Allocates the arrays an index keeps beside what make_fmi produces, unless
+// asked not to or HBM is short.
+static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
+  if (getenv("BWT_MI355X_COMPACT")) return;
+  const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  hipError_t ea = hipMalloc(&ix->d_sa, rows_all * 4);
+  if (ea == hipSuccess) ea = hipMalloc(&ix->d_isa, rows_all * 4);
+  if (ea == hipSuccess) ea = hipMalloc(&ix->d_text2, t2words * 4);
+  if (ea != hipSuccess) {
+    (void)hipGetLastError();
+    if (ix->d_sa) (void)hipFree(ix->d_sa);
+    if (ix->d_isa) (void)hipFree(ix->d_isa);
+    if (ix->d_text2) (void)hipFree(ix->d_text2);
+    ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+  }
+}
+
+// Everything after the suffix array: BWT bit-planes, sampled rows, the kept
+// arrays, rank blocks, C[], the k-mer table.  d_sa holds the n+1 rows (it is
+// ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
+// rows 1..n and *d_endloc then already holds the $ row.
+static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
+                      const uint8_t *bw, uint32_t *d_endloc, hipStream_t s) {
+  const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  if (bw) {
+    BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows, dim3((unsigned)div_up(ix->nblocks * 64, 256)),
+               dim3(256), 0, s, d_text, bw, n, d_endloc, ix->d_blocks, ix->nblocks);
+  } else {
+    (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
+    BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows,
+               d_endloc);
+    BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0, s,
+               d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
+  }
+  const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
+  BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
+  if (ix->d_sa) {
+    BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows,
+               ix->d_isa);
+    BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
+               t2words, ix->d_text2);
+  }
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
+  BWT_TRY(index_finish_from_planes(ix, s));  // synchronises the stream
+  if (ix->endloc > n) return set_error(kErrInternal, "no suffix-array row holds suffix 0");
+  return index_build_kmer_table(ix, s);
+}
+
 static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t s,
                                   bwtgpu_index **out) {
   bwtgpu_index *ix = nullptr;
   BWT_TRY(index_alloc(&ix, n));
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
-  // keep SA, ISA and the text in the index unless asked not to or HBM is short
-  const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
-  if (!getenv("BWT_MI355X_COMPACT")) {
-    hipError_t ea = hipMalloc(&ix->d_sa, rows_all * 4);
-    if (ea == hipSuccess) ea = hipMalloc(&ix->d_isa, rows_all * 4);
-    if (ea == hipSuccess) ea = hipMalloc(&ix->d_text2, t2words * 4);
-    if (ea != hipSuccess) {
-      (void)hipGetLastError();
-      if (ix->d_sa) (void)hipFree(ix->d_sa);
-      if (ix->d_isa) (void)hipFree(ix->d_isa);
-      if (ix->d_text2) (void)hipFree(ix->d_text2);
-      ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
-    }
-  }
+  alloc_kept_arrays(ix, n);
   int rc = cache_reserve(ix->d_sa ? 256 : ((size_t)n + 1) * 4, ws_bytes);
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return rc;
   }
   uint32_t *d_sa = ix->d_sa ? ix->d_sa : reinterpret_cast<uint32_t *>(g_cache.sa);
-  void *d_ws = g_cache.ws;
   uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
-  auto cleanup = [&]() {};
-  hipError_t e = hipSuccess;
   SaExtras extras;
-  rc = sa_build_impl(d_text, n, d_sa, d_ws, ws_bytes, s, &extras);
+  rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
-    const uint64_t rows = (uint64_t)n + 1;
-    if (extras.bw) {
-      (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
-      BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows, dim3((unsigned)div_up(ix->nblocks * 64, 256)),
-                 dim3(256), 0, s, d_text, extras.bw, n, d_endloc, ix->d_blocks, ix->nblocks);
-    } else {
-      (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
-      BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa,
-                 rows, d_endloc);
-      BWT_LAUNCH("emit_planes", k_emit_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0,
-                 s, d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
-    }
-    const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
-    BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns,
-               ix->d_idxs);
-    if (ix->d_sa) {
-      BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows_all, 256)), dim3(256), 0, s, d_sa,
-                 rows_all, ix->d_isa);
-      BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text,
-                 n, t2words, ix->d_text2);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) rc = set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
+    if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, s);
   }
-  if (rc == kOk) rc = index_finish_from_planes(ix, s);  // synchronises the stream
-  if (rc == kOk && ix->endloc > n) rc = set_error(kErrInternal, "no suffix-array row holds suffix 0");
-  if (rc == kOk) rc = index_build_kmer_table(ix, s);
-  cleanup();
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return rc;
   }
   *out = ix;
   return kOk;
+}
+
+// 256-bin histogram of the first four bases of every suffix, straight from the
+// packed text (bases past the end read as A, as in the sort).
+__global__ void __launch_bounds__(256)
+k_bucket_counts(const uint8_t *__restrict__ text, uint32_t n, unsigned long long *__restrict__ out) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t nbytes = (uint64_t)n / 4 + 1;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < n; q += stride) {
+    // the four suffixes that start in byte q
+    uint32_t w = (uint32_t)text[q] << 8;
+    if (q + 1 < nbytes) w |= text[q + 1];
+    // bits from base n on are not the text's: clear them
+    const uint64_t left = (uint64_t)n - 4 * q;  // bases from 4q to the end, >= 1
+    if (left < 8) w &= ~((1u << (16 - 2 * (uint32_t)left)) - 1u);
+    for (uint32_t k = 0; k < 4 && 4 * q + k < n; ++k) atomicAdd(&hist[(w >> (8 - 2 * k)) & 255u], 1u);
+  }
+  __syncthreads();
+  if (hist[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
 }  // namespace bwtgpu
@@ -254,6 +284,74 @@ int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n, 
              dim3(256), 0, s, d_text, d_sa, n, d_endloc, d_bwt);
   BWT_CHECK_LAUNCH();
   return kOk;
+}
+
+int bwtgpu_sa_bucket_counts(const uint8_t *d_text, uint32_t n, uint64_t h_counts[256], void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_text || !h_counts || n == 0) return set_error(kErrArg, "bad argument");
+  unsigned long long *d_out = nullptr;
+  BWT_HIP(hipMalloc(&d_out, 256 * sizeof(unsigned long long)));
+  hipError_t e = hipMemsetAsync(d_out, 0, 256 * sizeof(unsigned long long), s);
+  uint64_t groups = div_up(div_up(n, 4), 256 * 16);
+  if (groups > 4096) groups = 4096;
+  if (e == hipSuccess) {
+    BWT_LAUNCH("sa_bucket_counts", k_bucket_counts, dim3((unsigned)groups), dim3(256), 0, s, d_text, n, d_out);
+    e = hipGetLastError();
+  }
+  unsigned long long h[256];
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  if (e != hipSuccess) return set_error(kErrHip, "bucket counts: %s", hipGetErrorString(e));
+  for (int i = 0; i < 256; ++i) h_counts[i] = h[i];
+  return kOk;
+}
+
+int bwtgpu_sa_build_range(const uint8_t *d_text, uint32_t n, uint32_t bucket_lo, uint32_t bucket_hi,
+                          uint32_t *d_rows, uint8_t *d_bw, uint64_t capacity, uint64_t *row_begin,
+                          uint64_t *rows, uint32_t *endloc, void *d_ws, size_t ws_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_rows || !row_begin || !rows || !endloc) return set_error(kErrArg, "null argument");
+  SaRange range;
+  range.dlo = bucket_lo;
+  range.dhi = bucket_hi;
+  range.capacity = capacity;
+  SaExtras extras;
+  BWT_TRY(sa_build_core(d_text, n, d_rows, &range, d_ws, ws_bytes, s, &extras));
+  if (d_bw && range.rows) {
+    if (!extras.bw) return set_error(kErrInternal, "sharded build left no BWT symbols");
+    BWT_HIP(hipMemcpyAsync(d_bw, extras.bw, range.rows, hipMemcpyDeviceToDevice, s));
+  }
+  BWT_HIP(hipStreamSynchronize(s));
+  *row_begin = range.row_begin;
+  *rows = range.rows;
+  *endloc = range.endloc;
+  return kOk;
+}
+
+bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
+                                         const uint8_t *d_bw, uint32_t endloc, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!d_text || !d_sa || n == 0 || (d_bw && (endloc == 0 || endloc > n))) {
+    set_error(kErrArg, "bad argument");
+    return nullptr;
+  }
+  bwtgpu_index *ix = nullptr;
+  if (index_alloc(&ix, n) != kOk) return nullptr;
+  alloc_kept_arrays(ix, n);
+  int rc = cache_reserve(256, 256);
+  uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
+  if (rc == kOk && ix->d_sa &&
+      hipMemcpyAsync(ix->d_sa, d_sa, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    rc = set_error(kErrHip, "suffix array copy failed");
+  if (rc == kOk && d_bw && hipMemcpyAsync(d_endloc, &endloc, 4, hipMemcpyHostToDevice, s) != hipSuccess)
+    rc = set_error(kErrHip, "endloc upload failed");
+  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, s);
+  if (rc != kOk) {
+    bwtgpu_index_free(ix);
+    return nullptr;
+  }
+  return ix;
 }
 
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream) {

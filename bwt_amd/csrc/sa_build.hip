@@ -265,6 +265,26 @@ __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
   if (s < nsegs) tiles[s] = (segs[s].size + kPartTile - 1) / kPartTile;
 }
 
+// Sharded build, level 0: keeps the counts of the digits in [dlo, dhi), clears
+// the others, and reports how many suffixes precede the range and fall in it.
+__global__ void __launch_bounds__(256)
+k_restrict_level0(uint32_t *__restrict__ counts, uint32_t dlo, uint32_t dhi,
+                  uint64_t *__restrict__ out /* [0] before, [1] inside */) {
+  __shared__ unsigned long long before, inside;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) before = inside = 0;
+  __syncthreads();
+  const uint32_t c = counts[t];
+  if (t < dlo) atomicAdd(&before, (unsigned long long)c);
+  else if (t < dhi) atomicAdd(&inside, (unsigned long long)c);
+  if (t < dlo || t >= dhi) counts[t] = 0;
+  __syncthreads();
+  if (t == 0) {
+    out[0] = before;
+    out[1] = inside;
+  }
+}
+
 // Tile-local bucket order in LDS, then each bucket's run goes to the
 // segment's cursor for that bucket (one atomic per tile and bucket).  Order
 // inside a bucket is irrelevant at this stage.
@@ -280,7 +300,9 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
                const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
                const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors,
-               const uint32_t *__restrict__ leafmask, int gather_all) {
+               const uint32_t *__restrict__ leafmask, int gather_all, uint32_t dlo, uint32_t dhi) {
+  // dlo, dhi (level 0 only): suffixes whose first digit lies outside [dlo, dhi)
+  // belong to another shard of the build and are dropped here
   __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4], lmask[8];
   __shared__ uint32_t ids[kPartTile];
   __shared__ uint32_t kv[kPartTile];
@@ -295,6 +317,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     __syncthreads();
   }
   uint32_t id[kPartItems], key[kPartItems];
+  uint32_t mine = 0;  // bit i: item i is a suffix this launch places
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
     const uint32_t j = (uint32_t)i * kPartThreads + t;
@@ -302,9 +325,13 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
       if (IMPLICIT) {
         id[i] = row0 + j;
         const uint32_t k32 = key32(tb, (uint64_t)id[i] + depth);
-        atomicAdd(&hist[k32 >> 24], 1u);
+        const uint32_t d = k32 >> 24;
+        if (d < dlo || d >= dhi) continue;
+        mine |= 1u << i;
+        atomicAdd(&hist[d], 1u);
         key[i] = carried_word(tb, id[i], k32);
       } else {
+        mine |= 1u << i;
         id[i] = src[row0 + j];
         const uint32_t old = srckey[row0 + j];
         const uint32_t d = (old >> 16) & 255u;
@@ -334,8 +361,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    const uint32_t j = (uint32_t)i * kPartThreads + t;
-    if (j < count) {
+    if ((mine >> i) & 1u) {
       const uint32_t d = key[i] >> 24;
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
@@ -343,7 +369,8 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     }
   }
   __syncthreads();
-  for (uint32_t j = t; j < count; j += kPartThreads) {
+  const uint32_t placed = lstart[255] + hist[255];
+  for (uint32_t j = t; j < placed; j += kPartThreads) {
     const uint32_t k = kv[j], d = k >> 24;
     const uint32_t pos = gbase[d] + (j - lstart[d]);
     dst[pos] = ids[j];
@@ -863,15 +890,29 @@ static Layout layout_for(uint32_t n) {
 
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,
                   hipStream_t s, SaExtras *extras) {
+  return sa_build_core(d_text, n, d_sa, nullptr, d_ws, ws_bytes, s, extras);
+}
+
+// range == nullptr: the whole suffix array into d_sa (n+1 rows).
+// Otherwise only the suffixes whose first four bases, as a number, lie in
+// [range->dlo, range->dhi): their rows, in order, go to d_sa[0 ..) and the
+// range's place among all rows is reported in *range.
+int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *range, void *d_ws,
+                  size_t ws_bytes, hipStream_t s, SaExtras *extras) {
   if (extras) *extras = SaExtras{};
   if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
+  if (range && (range->dlo >= range->dhi || range->dhi > 256))
+    return set_error(kErrArg, "bucket range [%u, %u) is not inside [0, 256)", range->dlo, range->dhi);
+  if (range && n <= kLeafMax)
+    return set_error(kErrNeedsWholeText, "texts of up to %u bases are built whole", kLeafMax);
+  const uint32_t dlo = range ? range->dlo : 0u, dhi = range ? range->dhi : 256u;
   if (n == 0 || n > 0xFFFFFFF0u) return set_error(kErrArg, "text length %u out of range", n);
   if ((uintptr_t)d_ws & 255u) return set_error(kErrArg, "workspace must be 256-byte aligned");
   const Layout L = layout_for(n);
   if (ws_bytes < L.end) return set_error(kErrWorkspace, "SA workspace %zu < %zu bytes", ws_bytes, L.end);
   uint8_t *ws = reinterpret_cast<uint8_t *>(d_ws);
   uint32_t *tb = reinterpret_cast<uint32_t *>(ws + L.tb);
-  uint32_t *bufA = d_sa + 1;
+  uint32_t *bufA = range ? d_sa : d_sa + 1;
   uint32_t *bufB = reinterpret_cast<uint32_t *>(ws + L.bufB);
   uint32_t *keyA = reinterpret_cast<uint32_t *>(ws + L.keyA);
   uint32_t *keyB = reinterpret_cast<uint32_t *>(ws + L.keyB);
@@ -894,7 +935,7 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   BWT_HIP(hipMemcpyAsync(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
   // row 0 of the suffix array is the end-of-text suffix (histsortcomp.c:165)
   const uint32_t row0[1] = {n};
-  BWT_HIP(hipMemcpyAsync(d_sa, row0, 4, hipMemcpyHostToDevice, s));
+  if (!range) BWT_HIP(hipMemcpyAsync(d_sa, row0, 4, hipMemcpyHostToDevice, s));
   BWT_HIP(hipMemsetAsync(ghead, 0, 4, s));
 
   uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
@@ -934,18 +975,36 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
                  srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     }
+    if (range && depth == 0) {
+      // rows of other shards leave the picture here; the scan workspace is idle
+      uint64_t *d_out = reinterpret_cast<uint64_t *>(scanws);
+      uint64_t h_out[2] = {0, 0};
+      BWT_LAUNCH("sa_restrict_level0", k_restrict_level0, dim3(1), dim3(256), 0, s, counts, dlo, dhi, d_out);
+      BWT_HIP(hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, s));
+      BWT_HIP(hipStreamSynchronize(s));
+      range->row_begin = 1 + h_out[0];
+      range->rows = h_out[1];
+      if (range->rows > range->capacity)
+        return set_error(kErrArg, "bucket range holds %llu rows, the output has room for %llu",
+                         (unsigned long long)range->rows, (unsigned long long)range->capacity);
+      if (range->rows == 0) {
+        range->endloc = 0;
+        return kOk;
+      }
+    }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
                dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1);
+                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, dlo,
+                 dhi);
       key_age = 0;
     } else {
       // stored words shifted twice hold no bases for a further level: refresh all
       const int gather_all = key_age >= 1;
       BWT_LAUNCH("sa_part_scatter", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
                  src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask,
-                 gather_all);
+                 gather_all, 0u, 256u);
       key_age = gather_all ? 0 : key_age + 1;
     }
     BWT_CHECK_LAUNCH();
@@ -974,6 +1033,14 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
   BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
   BWT_HIP(hipStreamSynchronize(s));
   g_stats.v[2] = h_ctr.unresolved;
+  if (range) {
+    // the tie groups that are left need the ranks of suffixes of every shard
+    if (h_ctr.unresolved || nsegs)
+      return set_error(kErrNeedsWholeText,
+                       "%u rows of bucket range [%u, %u) tie beyond the bucket sort (repeats): build this text whole",
+                       h_ctr.unresolved, dlo, dhi);
+    range->endloc = h_ctr.endloc ? (uint32_t)(range->row_begin - 1 + h_ctr.endloc) : 0u;
+  }
   if (extras && !h_ctr.unresolved && !nsegs) {
     // every row came out of a leaf sort: its BWT symbol and the $ row are known
     extras->bw = bw;

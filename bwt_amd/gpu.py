@@ -201,6 +201,63 @@ def sa_build(d_text, n, ws=None):
     return sa
 
 
+def sa_bucket_counts(d_text, n):
+    """Suffixes per leading four-base string (256 counts, numpy uint64)."""
+    out = np.zeros(256, np.uint64)
+    check(_lib.load().bwtgpu_sa_bucket_counts(_ptr(d_text), n, out.ctypes.data_as(C.c_void_p), _stream()))
+    return out
+
+
+def sa_build_range(d_text, n, lo, hi, d_rows, d_bw=None, ws=None):
+    """One shard of the suffix array (see bwtgpu_sa_build_range) written to the
+    front of d_rows / d_bw.  Returns (row_begin, rows, endloc or 0)."""
+    lib = _lib.load()
+    wsb = int(lib.bwtgpu_sa_workspace_bytes(n))
+    if ws is None or ws.numel() < wsb:
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+    begin, rows, endloc = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    cap = d_rows.numel() if d_bw is None else min(d_rows.numel(), d_bw.numel())
+    check(lib.bwtgpu_sa_build_range(_ptr(d_text), n, lo, hi, _ptr(d_rows), _ptr(d_bw), cap, C.byref(begin),
+                                    C.byref(rows), C.byref(endloc), _ptr(ws), ws.numel(), _stream()))
+    return int(begin.value), int(rows.value), int(endloc.value)
+
+
+def build_index_from_sa(d_text, n, d_sa, d_bw=None, endloc=0):
+    """make_fmi's tail from a suffix array in HBM (n+1 rows)."""
+    assert d_sa.numel() >= n + 1 and (d_bw is None or d_bw.numel() >= n)
+    return GpuIndex(_lib.load().bwtgpu_index_build_from_sa(_ptr(d_text), n, _ptr(d_sa), _ptr(d_bw), endloc,
+                                                           _stream()))
+
+
+def build_index_sharded(d_text, n, group=None):
+    """make_fmi with the suffix array sorted in shards, one per rank of `group`
+    (bwt_amd.dist.build_sa_sharded); every rank returns its own copy of the
+    index.  Texts whose shards hold long repeats are built whole on every rank
+    instead.  Returns (index, "sharded" | "whole")."""
+    from . import dist as D
+
+    counts = sa_bucket_counts(d_text, n)
+    ws = torch.empty(int(_lib.load().bwtgpu_sa_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+
+    def build_range(lo, hi, rows_out, bw_out):
+        try:
+            return sa_build_range(d_text, n, lo, hi, rows_out, bw_out, ws)
+        except BwtGpuError as e:
+            if getattr(e, "code", 0) == -6:
+                raise D.NeedsWholeText(str(e))
+            raise
+
+    try:
+        endloc = D.build_sa_sharded(n, counts, build_range, sa, bw, group)
+    except D.NeedsWholeText:
+        del sa, bw, ws
+        return build_index_dev(d_text, n), "whole"
+    del ws
+    return build_index_from_sa(d_text, n, sa, bw[1:], endloc), "sharded"
+
+
 def sa_last_stats():
     st = (C.c_uint64 * 8)()
     check(_lib.load().bwtgpu_sa_last_stats(st))

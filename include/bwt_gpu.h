@@ -56,6 +56,28 @@ int bwtgpu_sa_build(const uint8_t *d_text, uint32_t n, uint32_t *d_sa,
  * the bucket phase, [3] prefix-doubling rounds, [4] deepest partition depth */
 int bwtgpu_sa_last_stats(uint64_t stats[8]);
 
+/* Sharded build.  A shard is the part of the suffix array whose suffixes begin
+ * with four bases that, read as a base-4 number (first base most significant,
+ * bases past the end of the text read as A), lie in [bucket_lo, bucket_hi):
+ * shards are contiguous row ranges, so the whole array is their concatenation
+ * in bucket order behind row 0.  The reference has one whole-array build
+ * (histsort, histsortcomp.c:161-180); its threads split the same way, by
+ * first base (histsortcomp.c:112-158).
+ * bwtgpu_sa_bucket_counts: how many suffixes begin with each of the 256
+ * strings (for choosing balanced ranges).
+ * bwtgpu_sa_build_range: d_rows[0 .. *rows) = rows [*row_begin, *row_begin +
+ * *rows) of the suffix array; d_bw (may be NULL) receives the BWT symbol of
+ * each of those rows, one per byte; *endloc = the row of suffix 0 if the shard
+ * holds it, else 0.  capacity = room in d_rows and d_bw, in rows.  Returns -6
+ * when the shard holds ties that only a whole-text build orders (long
+ * repeats): use bwtgpu_sa_build then.  Workspace as for bwtgpu_sa_build. */
+int bwtgpu_sa_bucket_counts(const uint8_t *d_text, uint32_t n, uint64_t h_counts[256],
+                            void *stream);
+int bwtgpu_sa_build_range(const uint8_t *d_text, uint32_t n, uint32_t bucket_lo,
+                          uint32_t bucket_hi, uint32_t *d_rows, uint8_t *d_bw,
+                          uint64_t capacity, uint64_t *row_begin, uint64_t *rows,
+                          uint32_t *endloc, void *d_ws, size_t ws_bytes, void *stream);
+
 /* Replaces sprintcbwt (histsortcomp.c:220-250): packed BWT without the $ row
  * ((n+3)/4 bytes at d_bwt) and the $ row number at *d_endloc. */
 int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n,
@@ -71,6 +93,13 @@ bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream
  * the next build; bwtgpu_release_cache() frees them. */
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream);
 int bwtgpu_release_cache(void);
+/* The tail of make_fmi (seqindex.c:168-188) from a suffix array already in HBM
+ * (n+1 rows, d_sa[0] = n), e.g. one assembled from shards.  d_bw (may be NULL)
+ * holds the BWT symbol of rows 1..n, one per byte, and endloc the $ row; when
+ * NULL both are read off the text.  The arrays are copied, not adopted. */
+bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n,
+                                         const uint32_t *d_sa, const uint8_t *d_bw,
+                                         uint32_t endloc, void *stream);
 /* Replaces the rebuild half of read_index (fileio.c:44-63): takes the stored
  * parts of an index (host pointers) and rebuilds the rank blocks on device.
  * h_idxs may be NULL (no locate on such an index). */
