@@ -330,16 +330,16 @@ __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *
 }
 
 // Table size: about one entry per base (the interval of a string of
-// floor(log4 n) bases holds a few rows), at most 4^13 entries (512 MiB);
+// floor(log4 n) bases holds a few rows), at most 4^15 entries (8 GiB);
 // BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT means none.
 static uint32_t kmer_table_k(uint32_t n) {
   if (getenv("BWT_MI355X_COMPACT")) return 0;
   if (const char *e = getenv("BWT_MI355X_KMER")) {
     const long k = strtol(e, nullptr, 10);
-    return k < 2 ? 0u : (k > 14 ? 14u : (uint32_t)k);
+    return k < 2 ? 0u : (k > 15 ? 15u : (uint32_t)k);
   }
   uint32_t k = 0;
-  while (k < 13 && (1ull << (2 * (k + 1))) <= (uint64_t)n) ++k;
+  while (k < 15 && (1ull << (2 * (k + 1))) <= (uint64_t)n) ++k;
   return k < 6 ? 0u : k;
 }
 

@@ -73,7 +73,10 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
     rows_of = shard_rows(counts, ranges)
     lo, hi = ranges[rank]
     begin, rows = rows_of[rank]
-    status = torch.zeros(3, dtype=torch.int64, device=sa.device)  # failed, endloc, rows built
+    # needs-whole-text ranks, endloc, rows built, failed ranks: every rank reaches
+    # the all-reduce whatever happened to its shard, so that no peer waits forever
+    status = torch.zeros(4, dtype=torch.int64, device=sa.device)
+    failure = None
     if rows:
         try:
             b, r, endloc = build_range(lo, hi, sa[begin:begin + rows], bw[begin:begin + rows])
@@ -83,7 +86,14 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
             status[2] = r
         except NeedsWholeText:
             status[0] = 1
+        except Exception as e:  # noqa: BLE001 - re-raised below, after the collective
+            failure = e
+            status[3] = 1
     dist.all_reduce(status, op=dist.ReduceOp.SUM, group=group)
+    if failure is not None:
+        raise failure
+    if int(status[3]):
+        raise RuntimeError(f"{int(status[3])} rank(s) failed to build their shard")
     if int(status[0]):
         raise NeedsWholeText("a shard holds long repeats; build this text whole on each rank")
     if int(status[2]) != n:

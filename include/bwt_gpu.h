@@ -123,7 +123,7 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
  * produces, the whole suffix array, its inverse and the text (8.25 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
  * every index also holds a table of the SA intervals of all strings of k bases
- * (k = floor(log4 n), at most 13; BWT_MI355X_KMER=<k> overrides), where
+ * (k = floor(log4 n), at most 15; BWT_MI355X_KMER=<k> overrides), where
  * searches of longer reads start.  Results are the same with or without them.
  * This call frees all four and leaves the rank blocks and the sampled suffix
  * array.  Setting BWT_MI355X_COMPACT in the environment makes every build and
