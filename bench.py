@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=50)
     ap.add_argument("--build-reps", type=int, default=3)
-    ap.add_argument("--cpu-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
     args = ap.parse_args()
