@@ -162,6 +162,9 @@ struct SaExtras {
 };
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
                   size_t ws_bytes, hipStream_t s, SaExtras *extras);
+// After a build: a part of its workspace that no by-product lives in, at
+// least 8 (n+1) + 2048 bytes, or null for tiny n.
+void *sa_workspace_free_region(uint32_t n, void *d_ws);
 // One shard of a build: the suffixes whose first four bases, read as a number
 // with the first base most significant, lie in [dlo, dhi).
 struct SaRange {

@@ -77,6 +77,98 @@ __global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
   if (j < rows) isa[sa[j]] = (uint32_t)j;
 }
 
+// Inverse of a suffix array too large for the Infinity Cache, in two steps so
+// that the 4-byte scatter stays inside a window the cache holds: first the
+// (position, row) pairs are dealt into up to 256 bins by the top bits of the
+// position -- bin b owns positions [b << shift, (b+1) << shift), so its pairs
+// fill exactly that range of the pair buffer and no counting pass is needed --
+// then the bins are emptied in order.
+constexpr int kIsaTile = 4096;
+
+__global__ void __launch_bounds__(256)
+k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
+                unsigned long long *__restrict__ cursors /* [256], start at b << shift */,
+                uint64_t *__restrict__ pairs) {
+  __shared__ uint32_t hist[256], lstart[256], fill[256], wsum[4];
+  __shared__ unsigned long long gbase[256];
+  __shared__ uint64_t stage[kIsaTile];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const uint64_t row0 = (uint64_t)blockIdx.x * kIsaTile;
+  hist[t] = 0;
+  fill[t] = 0;
+  __syncthreads();
+  uint32_t id[kIsaTile / 256];
+#pragma unroll
+  for (int i = 0; i < kIsaTile / 256; ++i) {
+    const uint64_t row = row0 + (uint64_t)i * 256 + t;
+    id[i] = row < rows ? sa[row] : 0xFFFFFFFFu;
+    if (row < rows) atomicAdd(&hist[id[i] >> shift], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = hist[t];
+  uint32_t v = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+  lstart[t] = pre + v - c;
+  gbase[t] = c ? atomicAdd(&cursors[t], (unsigned long long)c) : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kIsaTile / 256; ++i) {
+    const uint64_t row = row0 + (uint64_t)i * 256 + t;
+    if (row < rows) {
+      const uint32_t b = id[i] >> shift;
+      stage[lstart[b] + atomicAdd(&fill[b], 1u)] = ((uint64_t)row << 32) | id[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t placed = lstart[255] + hist[255];
+  for (uint32_t j = t; j < placed; j += 256) {
+    const uint64_t pr = stage[j];
+    const uint32_t b = (uint32_t)pr >> shift;
+    pairs[gbase[b] + (j - lstart[b])] = pr;
+  }
+}
+
+__global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
+                           uint32_t *__restrict__ isa) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows) return;
+  const uint64_t pr = pairs[j];
+  isa[(uint32_t)pr] = (uint32_t)(pr >> 32);
+}
+
+// ISA of the n+1 rows at d_sa.  scratch (may be null): 8 (n+1) + 2048 bytes
+// that nothing else is using.
+static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_isa, void *scratch,
+                                hipStream_t s) {
+  const uint64_t rows = (uint64_t)n + 1;
+  // up to 2^26 entries the array is cache-resident and one scatter is fastest
+  const bool force = getenv("BWT_MI355X_ISA_TWO_STEP") != nullptr;  // for tests on small texts
+  if (!scratch || (rows <= (1ull << 26) && !force)) {
+    BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa);
+    return kOk;
+  }
+  uint32_t shift = 0;
+  while (((uint64_t)n >> shift) > 255) ++shift;
+  unsigned long long h_cur[256];
+  for (uint32_t b = 0; b < 256; ++b) h_cur[b] = (unsigned long long)b << shift;
+  unsigned long long *d_cur = reinterpret_cast<unsigned long long *>(scratch);
+  uint64_t *pairs = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(scratch) + 2048);
+  BWT_HIP(hipMemcpyAsync(d_cur, h_cur, sizeof h_cur, hipMemcpyHostToDevice, s));
+  BWT_HIP(hipStreamSynchronize(s));  // h_cur leaves the stack
+  BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
+             rows, shift, d_cur, pairs);
+  BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, pairs, rows, d_isa);
+  BWT_CHECK_LAUNCH();
+  return kOk;
+}
+
 // text as 16-base words with base k at bits 2k (the layout of packed reads),
 // one zero guard word in front, zeros from base n on
 __global__ void k_make_text2(const uint8_t *__restrict__ text, uint32_t n, uint64_t nwords,
@@ -184,7 +276,7 @@ static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
 // ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
 // rows 1..n and *d_endloc then already holds the $ row.
 static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
-                      const uint8_t *bw, uint32_t *d_endloc, hipStream_t s) {
+                      const uint8_t *bw, uint32_t *d_endloc, void *isa_scratch, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
     BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows, dim3((unsigned)div_up(ix->nblocks * 64, 256)),
@@ -199,8 +291,7 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
   const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
   BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
   if (ix->d_sa) {
-    BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows,
-               ix->d_isa);
+    BWT_TRY(inverse_suffix_array(d_sa, n, ix->d_isa, isa_scratch, s));
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
   }
@@ -229,7 +320,8 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
     if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
-    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, s);
+    // the sort's id and key buffers (12 bytes per row, contiguous) are free again
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, sa_workspace_free_region(n, g_cache.ws), s);
   }
   if (rc != kOk) {
     bwtgpu_index_free(ix);
@@ -346,7 +438,14 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     rc = set_error(kErrHip, "suffix array copy failed");
   if (rc == kOk && d_bw && hipMemcpyAsync(d_endloc, &endloc, 4, hipMemcpyHostToDevice, s) != hipSuccess)
     rc = set_error(kErrHip, "endloc upload failed");
-  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, s);
+  void *scratch = nullptr;
+  if (rc == kOk && ix->d_sa && (uint64_t)n + 1 > (1ull << 26) &&
+      hipMalloc(&scratch, ((size_t)n + 1) * 8 + 2048) != hipSuccess) {
+    (void)hipGetLastError();
+    scratch = nullptr;  // the one-step scatter needs none
+  }
+  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, scratch, s);
+  if (scratch) (void)hipFree(scratch);  // emit_index has synchronised the stream
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return nullptr;

@@ -479,6 +479,128 @@ __device__ __forceinline__ void leaf_load_sort(const uint32_t *__restrict__ tb,
   for (int m = 0; m < E; ++m) lds[pad(t * E + m)] = r[m];
 }
 
+constexpr uint32_t kLeafBuckets = 4096;   // LDS buckets of the interpolation sort
+constexpr uint32_t kLeafBucketMax = 32;   // a fuller bucket sends the leaf to the bitonic network
+
+// Sorts a leaf whose keys are spread evenly (any text without long repeats):
+// one counting pass over kLeafBuckets buckets chosen by linear interpolation
+// between the smallest and largest key -- monotone in the key, so buckets are
+// in order -- then an insertion sort inside each bucket (0.9 elements on
+// average).  Leaves the words in `lds` in the blocked layout and returns true;
+// returns false (lds untouched in any way that matters) when some bucket holds
+// more than kLeafBucketMax words.  All threads of the workgroup call it.
+__device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb,
+                                                 const uint32_t *__restrict__ src,
+                                                 const uint32_t *__restrict__ srckey, uint32_t start,
+                                                 uint32_t size, uint32_t depth, uint64_t *lds,
+                                                 uint32_t *cnt, uint32_t *red, uint32_t t) {
+  constexpr int E = kLeafMax / 256;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  uint64_t r[E];
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t j = (uint32_t)m * 256 + t;
+    r[m] = ~0ull;
+    if (j < size) {
+      r[m] = leaf_fetch(tb, src, srckey, start + j, depth);
+      const uint32_t k = word_key(r[m]);
+      kmin = k < kmin ? k : kmin;
+      kmax = k > kmax ? k : kmax;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < (int)(kLeafBuckets / 256); ++q) cnt[q * 256 + t] = 0;
+  for (int off = 32; off; off >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  if (lane == 0) {
+    red[wave] = kmin;
+    red[4 + wave] = kmax;
+  }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    kmin = red[w] < kmin ? red[w] : kmin;
+    kmax = red[4 + w] > kmax ? red[4 + w] : kmax;
+  }
+  const float scale = (float)kLeafBuckets / (float)(kmax - kmin + 1u);
+  uint32_t bucket[E], slot[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t j = (uint32_t)m * 256 + t;
+    if (j < size) {
+      uint32_t b = (uint32_t)((float)(word_key(r[m]) - kmin) * scale);
+      b = b < kLeafBuckets ? b : kLeafBuckets - 1;
+      bucket[m] = b;
+      slot[m] = atomicAdd(&cnt[b], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the bucket counts; thread t owns buckets [16 t, 16 t + 16)
+  constexpr int B = kLeafBuckets / 256;
+  uint32_t own[B], sum = 0, fullest = 0;
+#pragma unroll
+  for (int q = 0; q < B; ++q) {
+    own[q] = cnt[t * B + q];
+    sum += own[q];
+    fullest = own[q] > fullest ? own[q] : fullest;
+  }
+  uint32_t v = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  for (int off = 32; off; off >>= 1) {
+    const uint32_t u = __shfl_xor(fullest, off, 64);
+    fullest = u > fullest ? u : fullest;
+  }
+  __syncthreads();  // red[] is read by every thread above before it is reused
+  if (lane == 63) red[wave] = v;
+  if (lane == 0) red[4 + wave] = fullest;
+  __syncthreads();
+  uint32_t first = v - sum;
+  for (uint32_t w = 0; w < wave; ++w) first += red[w];
+  fullest = red[4] > red[5] ? red[4] : red[5];
+  fullest = red[6] > fullest ? red[6] : fullest;
+  fullest = red[7] > fullest ? red[7] : fullest;
+  if (fullest > kLeafBucketMax) return false;
+  {
+    uint32_t run = first;
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      cnt[t * B + q] = run;
+      run += own[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t j = (uint32_t)m * 256 + t;
+    if (j < size) lds[pad(cnt[bucket[m]] + slot[m])] = r[m];
+  }
+  __syncthreads();
+  {
+    uint32_t lo = first;
+#pragma unroll 1
+    for (int q = 0; q < B; ++q) {
+      const uint32_t c = own[q];
+      for (uint32_t a = 1; a < c; ++a) {
+        const uint64_t x = lds[pad(lo + a)];
+        uint32_t b = a;
+        while (b > 0 && lds[pad(lo + b - 1)] > x) {
+          lds[pad(lo + b)] = lds[pad(lo + b - 1)];
+          --b;
+        }
+        lds[pad(lo + b)] = x;
+      }
+      lo += c;
+    }
+  }
+  return true;
+}
+
 // Order of two suffixes that agree on their first `off` bases: -1 if a comes
 // first, +1 if b does, 0 if still undecided after kDeepWords words.  Past the
 // end of the text a suffix reads as A's; two suffixes equal all the way are
@@ -509,6 +631,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
   __shared__ uint32_t wred[4], wmax[4];
+  __shared__ uint32_t bcnt[kLeafBuckets], bred[8];
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
@@ -527,7 +650,9 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   if (t < kLeafMax / 32) settled[t] = 0;
   uint32_t P = 2;
   while (P < size) P <<= 1;
-  if (P == 4096) {
+  if (size > 256 && leaf_bucket_sort(tb, src, srckey, start, size, depth, keys, bcnt, bred, t)) {
+    // sorted by the counting pass
+  } else if (P == 4096) {
     leaf_load_sort<4>(tb, src, srckey, start, size, depth, keys, t);
   } else if (P == 2048) {
     leaf_load_sort<3>(tb, src, srckey, start, size, depth, keys, t);
@@ -648,8 +773,8 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
       const uint64_t w = keys[pad(j)];
       const uint32_t id = word_id(w);
       run = hv[k] > run ? hv[k] : run;
-      outv[k] = ((uint64_t)run << 32) | id;
-      bw[start + j] = (uint8_t)(w & 3u);
+      // head row relative to the leaf (12 bits), BWT symbol, id: one word per row
+      outv[k] = ((uint64_t)(w & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
       if (id == 0) ctr->endloc = 1 + start + j;
     }
   }
@@ -663,7 +788,8 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   for (uint32_t j = t; j < size; j += 256) {
     const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
-    ghead[1 + start + j] = (uint32_t)(o >> 32);
+    ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
+    bw[start + j] = (uint8_t)(o >> 44);
   }
 }
 
@@ -886,6 +1012,14 @@ static Layout layout_for(uint32_t n) {
   L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
   L.end = off;
   return L;
+}
+
+void *sa_workspace_free_region(uint32_t n, void *d_ws) {
+  const Layout L = layout_for(n);
+  // bufB, keyA, keyB follow each other: 12 (n+1) bytes and some alignment
+  static_assert(sizeof(uint32_t) * 3 >= 8 + 0, "three words per row hold one pair");
+  if (L.keyB + ((size_t)n + 1) * 4 - L.bufB < ((size_t)n + 1) * 8 + 2048) return nullptr;
+  return reinterpret_cast<uint8_t *>(d_ws) + L.bufB;
 }
 
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws, size_t ws_bytes,

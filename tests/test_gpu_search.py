@@ -266,3 +266,20 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
             np.testing.assert_array_equal(got, want, err_msg=f"{name} m={m}")
     loads, _, _ = full.search_loads(torch.from_numpy(reads.reshape(-1)).cuda(), 70, 3000)
     assert loads["kmer_entries_8B"] == (3000 if k >= 2 else 0)
+
+
+@pytest.mark.parametrize("n", [5000, 100003, 3000000])
+def test_two_step_inverse_suffix_array(oracle, gpu, n, monkeypatch):
+    """Large texts build the inverse suffix array by partition + fill; forced
+    here on small ones.  Every search that ends in the text comparison reads it."""
+    text = oracle.gen_genome(n, 555 + n)
+    fo = oracle.make_fmi(text, n)
+    monkeypatch.setenv("BWT_MI355X_ISA_TWO_STEP", "1")
+    ix = gpu.build_index(text, n)
+    monkeypatch.delenv("BWT_MI355X_ISA_TWO_STEP")
+    R, m = 20000, 60
+    reads = _mutated_reads(synth.unpack(text, n), n, R, m, 77)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    sp, ep = ix.search(torch.from_numpy(reads.reshape(-1)).cuda(), m, R)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
