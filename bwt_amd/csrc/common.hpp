@@ -27,6 +27,16 @@ enum : int {
 
 int set_error(int code, const char *fmt, ...);
 
+// runtime.hip: device buffers that are reused across indexes (exact-size
+// matches); pool_release_idle() returns the idle ones to the driver.
+hipError_t pool_alloc(void **out, size_t bytes);
+void pool_free(void *p);
+void pool_release_idle();
+template <class T>
+inline hipError_t pool_alloc(T **out, size_t bytes) {
+  return pool_alloc(reinterpret_cast<void **>(out), bytes);
+}
+
 #define BWT_HIP(expr)                                                        \
   do {                                                                       \
     hipError_t e__ = (expr);                                                 \

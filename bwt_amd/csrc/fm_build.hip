@@ -259,14 +259,14 @@ static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
 static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
   if (getenv("BWT_MI355X_COMPACT")) return;
   const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
-  hipError_t ea = hipMalloc(&ix->d_sa, rows_all * 4);
-  if (ea == hipSuccess) ea = hipMalloc(&ix->d_isa, rows_all * 4);
-  if (ea == hipSuccess) ea = hipMalloc(&ix->d_text2, t2words * 4);
+  hipError_t ea = pool_alloc(&ix->d_sa, rows_all * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, rows_all * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
   if (ea != hipSuccess) {
     (void)hipGetLastError();
-    if (ix->d_sa) (void)hipFree(ix->d_sa);
-    if (ix->d_isa) (void)hipFree(ix->d_isa);
-    if (ix->d_text2) (void)hipFree(ix->d_text2);
+    pool_free(ix->d_sa);
+    pool_free(ix->d_isa);
+    pool_free(ix->d_text2);
     ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   }
 }
@@ -361,6 +361,7 @@ extern "C" {
 
 int bwtgpu_release_cache(void) {
   g_cache.release();
+  pool_release_idle();
   return kOk;
 }
 

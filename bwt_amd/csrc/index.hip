@@ -329,9 +329,10 @@ __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *
   dst[q] = o;
 }
 
-// Table size: about one entry per base (the interval of a string of
-// floor(log4 n) bases holds a few rows), at most 4^15 entries (8 GiB);
-// BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT means none.
+// Table size: the smallest k with 4^k >= n, so that the interval of a string
+// of k bases is a single row more often than not, at most 4^15 entries
+// (8 GiB); BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT
+// means none.
 static uint32_t kmer_table_k(uint32_t n) {
   if (getenv("BWT_MI355X_COMPACT")) return 0;
   if (const char *e = getenv("BWT_MI355X_KMER")) {
@@ -339,7 +340,7 @@ static uint32_t kmer_table_k(uint32_t n) {
     return k < 2 ? 0u : (k > 15 ? 15u : (uint32_t)k);
   }
   uint32_t k = 0;
-  while (k < 15 && (1ull << (2 * (k + 1))) <= (uint64_t)n) ++k;
+  while (k < 15 && (1ull << (2 * k)) < (uint64_t)n) ++k;
   return k < 6 ? 0u : k;
 }
 
@@ -348,10 +349,10 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   if (K == 0) return kOk;
   const uint64_t entries = 1ull << (2 * K);
   uint2 *tab = nullptr, *tmp = nullptr;
-  if (hipMalloc(&tab, entries * sizeof(uint2)) != hipSuccess ||
-      hipMalloc(&tmp, (entries / 4) * sizeof(uint2)) != hipSuccess) {
+  if (pool_alloc(&tab, entries * sizeof(uint2)) != hipSuccess ||
+      pool_alloc(&tmp, (entries / 4) * sizeof(uint2)) != hipSuccess) {
     (void)hipGetLastError();  // short of memory: searches start from the first base instead
-    if (tab) (void)hipFree(tab);
+    pool_free(tab);
     return kOk;
   }
   // level j lives in tab when K - j is even, in tmp otherwise, so level K ends in tab
@@ -369,9 +370,10 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(tmp);
+  if (e != hipSuccess) (void)hipDeviceSynchronize();
+  pool_free(tmp);
   if (e != hipSuccess) {
-    (void)hipFree(tab);
+    pool_free(tab);
     return set_error(kErrHip, "k-mer table build: %s", hipGetErrorString(e));
   }
   ix->d_kmer = tab;
@@ -387,10 +389,10 @@ int index_alloc(bwtgpu_index **out, uint32_t n) {
   ix->nblocks = (uint64_t)n / 64 + 1;
   ix->nsym = (uint64_t)n / kSymBases + 1;
   BWT_HIP(hipGetDevice(&ix->device));
-  hipError_t e = hipMalloc(&ix->d_blocks, ix->nblocks * sizeof(IndexBlock));
-  if (e == hipSuccess) e = hipMalloc(&ix->d_sym, 4 * ix->nsym * sizeof(SymBlock));
+  hipError_t e = pool_alloc(&ix->d_blocks, ix->nblocks * sizeof(IndexBlock));
+  if (e == hipSuccess) e = pool_alloc(&ix->d_sym, 4 * ix->nsym * sizeof(SymBlock));
   if (e == hipSuccess)
-    e = hipMalloc(&ix->d_idxs, (((uint64_t)n >> kDevSampleShift) + 1) * sizeof(uint32_t));
+    e = pool_alloc(&ix->d_idxs, (((uint64_t)n >> kDevSampleShift) + 1) * sizeof(uint32_t));
   if (e != hipSuccess) {
     bwtgpu_index_free(ix);
     return set_error(kErrHip, "hipMalloc of index for n=%u failed: %s", n, hipGetErrorString(e));
@@ -405,7 +407,7 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
   const uint32_t ntiles = (uint32_t)div_up(nb, kTileBlocks);
   uint4 *d_tiles = nullptr;
   uint32_t *d_C = nullptr;
-  BWT_HIP(hipMalloc(&d_tiles, (size_t)ntiles * sizeof(uint4) + 64));
+  BWT_HIP(pool_alloc(&d_tiles, (size_t)ntiles * sizeof(uint4) + 64));
   d_C = reinterpret_cast<uint32_t *>(d_tiles + ntiles);
   BWT_LAUNCH("rank_tile_reduce", k_rank_tile_reduce, dim3(ntiles), dim3(kTileThreads), 0, s,
              ix->d_blocks, nb, ix->n, d_tiles);
@@ -417,7 +419,8 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  (void)hipFree(d_tiles);
+  if (e != hipSuccess) (void)hipDeviceSynchronize();
+  pool_free(d_tiles);
   if (e != hipSuccess) return set_error(kErrHip, "rank table build: %s", hipGetErrorString(e));
   if (ix->C[4] != ix->n + 1)
     return set_error(kErrInternal, "rank table totals %u != n+1 = %u", ix->C[4], ix->n + 1);
@@ -432,13 +435,19 @@ extern "C" {
 
 void bwtgpu_index_free(bwtgpu_index *ix) {
   if (!ix) return;
-  if (ix->d_blocks) (void)hipFree(ix->d_blocks);
-  if (ix->d_sym) (void)hipFree(ix->d_sym);
-  if (ix->d_idxs) (void)hipFree(ix->d_idxs);
-  if (ix->d_sa) (void)hipFree(ix->d_sa);
-  if (ix->d_isa) (void)hipFree(ix->d_isa);
-  if (ix->d_text2) (void)hipFree(ix->d_text2);
-  if (ix->d_kmer) (void)hipFree(ix->d_kmer);
+  // the buffers go back to the pool for the next index: nothing may still be using them
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != ix->device) (void)hipSetDevice(ix->device);
+  (void)hipDeviceSynchronize();
+  pool_free(ix->d_blocks);
+  pool_free(ix->d_sym);
+  pool_free(ix->d_idxs);
+  pool_free(ix->d_sa);
+  pool_free(ix->d_isa);
+  pool_free(ix->d_text2);
+  pool_free(ix->d_kmer);
+  if (cur != ix->device) (void)hipSetDevice(cur);
   delete ix;
 }
 
@@ -520,10 +529,12 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   if (!ix) return set_error(kErrArg, "null index");
   BWT_HIP(hipSetDevice(ix->device));
   BWT_HIP(hipDeviceSynchronize());  // searches in flight may still read the arrays
-  if (ix->d_sa) (void)hipFree(ix->d_sa);
-  if (ix->d_isa) (void)hipFree(ix->d_isa);
-  if (ix->d_text2) (void)hipFree(ix->d_text2);
-  if (ix->d_kmer) (void)hipFree(ix->d_kmer);
+  // compacting is for saving memory: these go back to the driver, not to the pool
+  pool_free(ix->d_sa);
+  pool_free(ix->d_isa);
+  pool_free(ix->d_text2);
+  pool_free(ix->d_kmer);
+  pool_release_idle();
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
   ix->kmer_k = 0;

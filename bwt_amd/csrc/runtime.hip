@@ -1,6 +1,9 @@
 // Library plumbing: device selection, error strings, per-launch timing.
 #include <cstring>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.hpp"
 
 namespace bwtgpu {
@@ -13,6 +16,85 @@ int set_error(int code, const char *fmt, ...) {
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
   return code;
+}
+
+// Device buffers of indexes come and go in a few sizes (every index of one
+// text length uses the same ones), and hipMalloc of hundreds of megabytes costs
+// more than the kernels that fill them.  Freed buffers wait here, keyed by
+// device and exact size, for the next request of that size.
+namespace {
+struct Pooled {
+  void *p;
+  size_t bytes;
+  int device;
+};
+std::mutex g_pool_mu;
+std::unordered_map<void *, Pooled> g_live;  // handed out by pool_alloc
+std::vector<Pooled> g_idle;
+constexpr size_t kPoolMaxIdle = 48;
+}  // namespace
+
+hipError_t pool_alloc(void **out, size_t bytes) {
+  *out = nullptr;
+  if (bytes == 0) bytes = 256;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (size_t i = 0; i < g_idle.size(); ++i)
+      if (g_idle[i].bytes == bytes && g_idle[i].device == dev) {
+        const Pooled hit = g_idle[i];
+        g_idle.erase(g_idle.begin() + (long)i);
+        g_live[hit.p] = hit;
+        *out = hit.p;
+        return hipSuccess;
+      }
+  }
+  void *p = nullptr;
+  e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    // idle buffers may be what is in the way: give them back and try once more
+    (void)hipGetLastError();
+    pool_release_idle();
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  g_live[p] = Pooled{p, bytes, dev};
+  *out = p;
+  return hipSuccess;
+}
+
+// The caller has made sure that no work in flight still uses the buffer.
+void pool_free(void *p) {
+  if (!p) return;
+  Pooled item{p, 0, 0};
+  bool known = false, keep = false;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) {
+      item = it->second;
+      g_live.erase(it);
+      known = true;
+      if (g_idle.size() < kPoolMaxIdle) {
+        g_idle.push_back(item);
+        keep = true;
+      }
+    }
+  }
+  (void)known;
+  if (!keep) (void)hipFree(p);
+}
+
+void pool_release_idle() {
+  std::vector<Pooled> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    drop.swap(g_idle);
+  }
+  for (const Pooled &d : drop) (void)hipFree(d.p);
 }
 
 TimingState &timing() {

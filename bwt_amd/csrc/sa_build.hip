@@ -1129,14 +1129,14 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
                dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_scatter", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
+      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
                  src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, dlo,
                  dhi);
       key_age = 0;
     } else {
       // stored words shifted twice hold no bases for a further level: refresh all
       const int gather_all = key_age >= 1;
-      BWT_LAUNCH("sa_part_scatter", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
+      BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
                  src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask,
                  gather_all, 0u, 256u);
       key_age = gather_all ? 0 : key_age + 1;

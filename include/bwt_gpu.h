@@ -88,9 +88,10 @@ int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n,
  * 32nd SA row (seqindex.c:173-176), BWT, rank blocks, C[].  h_text is the
  * packed text on the host (n/4+1 bytes).  The SA never leaves the device. */
 bwtgpu_index *bwtgpu_index_build(const uint8_t *h_text, uint32_t n, void *stream);
-/* Same from a packed text already in HBM.  Both keep the suffix array and
- * workspace buffers (about 21 bytes per base) cached on the calling thread for
- * the next build; bwtgpu_release_cache() frees them. */
+/* Same from a packed text already in HBM.  Both keep the workspace buffers
+ * (about 21 bytes per base) cached on the calling thread for the next build,
+ * and the buffers of freed indexes are kept for the next index of the same
+ * size; bwtgpu_release_cache() returns all of that to the driver. */
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream);
 int bwtgpu_release_cache(void);
 /* The tail of make_fmi (seqindex.c:168-188) from a suffix array already in HBM
@@ -123,7 +124,7 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
  * produces, the whole suffix array, its inverse and the text (8.25 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
  * every index also holds a table of the SA intervals of all strings of k bases
- * (k = floor(log4 n), at most 15; BWT_MI355X_KMER=<k> overrides), where
+ * (k = ceil(log4 n), at most 15; BWT_MI355X_KMER=<k> overrides), where
  * searches of longer reads start.  Results are the same with or without them.
  * This call frees all four and leaves the rank blocks and the sampled suffix
  * array.  Setting BWT_MI355X_COMPACT in the environment makes every build and
