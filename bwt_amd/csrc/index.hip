@@ -316,17 +316,30 @@ __global__ void k_thin_samples(const uint32_t *__restrict__ dense, uint64_t nsto
 // rank queries of a wave fall on neighbouring blocks.
 __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
                              uint32_t j) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= (1ull << (2 * (j + 1)))) return;
-  const uint32_t c = (uint32_t)(q >> (2 * j));
-  const uint2 p = src[q & ((1ull << (2 * j)) - 1ull)];
-  uint2 o = make_uint2(0u, 0u);
-  if (p.y > p.x) {
-    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
-    const uint32_t sp = occ_c(v, c, nlo, nhi, p.x), ep = occ_c(v, c, nlo, nhi, p.y);
-    if (ep > sp) o = make_uint2(sp, ep);
+  // one thread per string x of j bases: the two blocks its interval ends fall
+  // in serve all four extensions c.x
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t parents = 1ull << (2 * j);
+  if (p >= parents) return;
+  const uint2 iv = src[p];
+  uint2 o[4] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
+  if (iv.y > iv.x) {
+    const uint32_t a = iv.x - (iv.x > v.endloc), b = iv.y - (iv.y > v.endloc);  // seqindex.c:222-223
+    const IndexBlock *ba = v.blocks + (a >> 6), *bb = v.blocks + (b >> 6);
+    const uint4 oa = *reinterpret_cast<const uint4 *>(ba->occ), ob = *reinterpret_cast<const uint4 *>(bb->occ);
+    const uint64_t la = ba->lo, ha = ba->hi, lb = bb->lo, hb = bb->hi;
+    const uint64_t ma = low_mask(a & 63u), mb = low_mask(b & 63u);
+    const uint32_t occa[4] = {oa.x, oa.y, oa.z, oa.w}, occb[4] = {ob.x, ob.y, ob.z, ob.w};
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+      const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+      const uint32_t sp = occa[c] + (uint32_t)__popcll((la ^ nlo) & (ha ^ nhi) & ma);
+      const uint32_t ep = occb[c] + (uint32_t)__popcll((lb ^ nlo) & (hb ^ nhi) & mb);
+      if (ep > sp) o[c] = make_uint2(sp, ep);
+    }
   }
-  dst[q] = o;
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) dst[(uint64_t)c * parents + p] = o[c];
 }
 
 // Table size: the smallest k with 4^k >= n, so that the interval of a string
@@ -364,8 +377,8 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   if (e == hipSuccess) e = hipStreamSynchronize(s);  // first[] leaves the stack
   const IndexView v = view_of(ix);
   for (uint32_t j = 1; j < K && e == hipSuccess; ++j) {
-    const uint64_t out = 1ull << (2 * (j + 1));
-    BWT_LAUNCH("kmer_level", k_kmer_level, dim3((unsigned)div_up(out, 256)), dim3(256), 0, s, v, buf(j),
+    const uint64_t parents = 1ull << (2 * j);
+    BWT_LAUNCH("kmer_level", k_kmer_level, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v, buf(j),
                buf(j + 1), j);
     e = hipGetLastError();
   }
