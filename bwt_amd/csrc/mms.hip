@@ -33,11 +33,24 @@ __device__ __forceinline__ void occ_all(const IndexView &v, uint32_t idx, uint32
   out[3] = occ.w + (uint32_t)__popcll(lo & hi & m);
 }
 
+// base p of the text (p < n) from the 16-base words kept with the suffix array
+__device__ __forceinline__ uint32_t text_base2(const IndexView &v, uint32_t p) {
+  return (v.text2[1 + (p >> 4)] >> (2u * (p & 15u))) & 3u;
+}
+
 // mms (seqindex.c:314-351).  Symbols 0..3 are bases, 5 is N: trailing Ns are
 // skipped (:317-320), an inner N is read as the base with the most
 // occurrences in the current interval, lowest base on ties (:330-340).
 // A pattern made of Ns only (the reference reads before the buffer there)
 // returns its length with an empty interval.
+//
+// Two shortcuts, both leaving the results as the loop alone gives them: the
+// search starts from the k-mer table entry of the last k bases when none of
+// them is N and the string occurs; and once the interval is a single row of an
+// index that keeps SA, ISA and the text, the remaining bases are compared with
+// the text in front of that row's suffix -- an N there always agrees, being
+// read as the one base that precedes the row -- and the last non-empty
+// interval is the row of the suffix that many bases earlier.
 __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int len,
                                        uint32_t *sp_out, uint32_t *ep_out) {
   int skips = 0;
@@ -52,12 +65,43 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
   }
   uint32_t c = pat[len - 1] & 3u;
   uint32_t start = c_of(C, c), end = c_of(C, c + 1);
+  int i = len - 2;
+  const int K = (int)v.kmer_k;
+  if (K && len >= K) {
+    uint32_t x = 0;
+    bool plain = true;
+    for (int k = 0; k < K; ++k) {
+      const uint32_t raw = pat[len - K + k];
+      plain = plain && raw != 5;
+      x = (x << 2) | (raw & 3u);
+    }
+    if (plain) {
+      const uint2 e = v.kmer[x];
+      if (e.y > e.x) {
+        start = e.x;
+        end = e.y;
+        i = len - K - 1;
+      }
+    }
+  }
   uint32_t sp = start, ep = end;
-  int i;
-  for (i = len - 2; i >= 0; --i) {
+  for (; i >= 0; --i) {
     if (end <= start) break;
     sp = start;
     ep = end;
+    if (v.sa && end - start == 1) {
+      const uint32_t pos = v.sa[start];
+      uint32_t k = 0;  // bases that agree with the text in front of pos
+      while ((int)k <= i && k < pos) {
+        const uint32_t raw = pat[i - (int)k];
+        if (raw != 5 && (raw & 3u) != text_base2(v, pos - 1 - k)) break;
+        ++k;
+      }
+      const uint32_t row = k ? v.isa[pos - k] : start;
+      *sp_out = row;
+      *ep_out = row + 1;
+      return len - 1 - i + (int)k + skips;
+    }
     const uint32_t raw = pat[i];
     if (raw == 5) {
       uint32_t a[4], b[4];
@@ -138,7 +182,7 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
       if (got >= anchor) {  // :119-127
         res[dir]++;
         len -= got;
-        res[2 + dir] = sp <= v.n ? unc_sa_dev(v, sp) : 0xFFFFFFFFu;
+        res[2 + dir] = sp > v.n ? 0xFFFFFFFFu : v.sa ? v.sa[sp] : unc_sa_dev(v, sp);
       } else {
         len -= 1;  // :130
       }

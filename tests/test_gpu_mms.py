@@ -42,6 +42,8 @@ def test_mms_mismatching_reads_and_scalar_call(oracle, gpu):
     fo = oracle.make_fmi(text, n)
     ix = gpu.build_index(text, n)
     reads, _ = oracle.gen_reads(text, n, R, m, 22)
+    from bwt_amd import synth
+    bases = synth.unpack(text, n)
     rng = np.random.default_rng(3)
     for r in range(R):
         for _ in range(rng.integers(0, 3)):
@@ -49,9 +51,20 @@ def test_mms_mismatching_reads_and_scalar_call(oracle, gpu):
             reads[r, p] = (reads[r, p] + 1 + rng.integers(0, 3)) & 3
         if r % 5 == 0:
             reads[r, rng.integers(0, m)] = 5
-    got, sp, ep = _mms(gpu, ix, reads)
-    for r in range(R):
-        assert (int(got[r]), int(sp[r]), int(ep[r])) == oracle.mms(fo, reads[r]), r
+        if r % 7 == 0:   # an N among the last bases: no table start for this read
+            reads[r, m - 1 - rng.integers(0, 12)] = 5
+        if r % 11 == 0:  # the read ends with the first bases of the text: the match runs into its start
+            k = int(rng.integers(1, m))
+            reads[r, m - k:] = bases[:k]
+    want = [oracle.mms(fo, reads[r]) for r in range(R)]
+    # index with SA/ISA/text and table, index from stored parts (table only), bare rank blocks
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    for name, index in (("full", ix), ("from parts", lean)):
+        got, sp, ep = _mms(gpu, index, reads)
+        assert [(int(a), int(b), int(c)) for a, b, c in zip(got, sp, ep)] == want, name
+    lean.compact()
+    got, sp, ep = _mms(gpu, lean, reads)
+    assert [(int(a), int(b), int(c)) for a, b, c in zip(got, sp, ep)] == want
     hl = C.CDLL(_lib.LIB_PATH)
     hl.make_fmi.restype = C.c_void_p
     hl.make_fmi.argtypes = [C.c_void_p, C.c_int]
