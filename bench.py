@@ -96,9 +96,14 @@ def main():
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0,
+                    help="seconds the multi-rank sharded build may take before it is reported as stuck")
     ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
     args = ap.parse_args()
 
+    if os.environ.get("BWT_BENCH_TRACE_AFTER"):  # debugging aid: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BWT_BENCH_TRACE_AFTER"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +122,8 @@ def main():
     G.init(local_rank)
 
     n, R, m = args.genome_bp, args.reads, args.read_len
+    # timing words travel as device tensors over RCCL, as host tensors over gloo
+    red_dev = "cpu" if os.environ.get("BWT_BENCH_REHEARSAL") else "cuda"
 
     def barrier():
         torch.cuda.synchronize()
@@ -148,33 +155,8 @@ def main():
     sa_stats = G.sa_last_stats()
     build_s = float(np.median(build_ms)) / 1e3
 
-    # ---- HP1 sharded: one shard of the suffix array per rank, broadcast into place ----
     sharded = None
-    if dist is not None:
-        try:
-            ixs, how = G.build_index_sharded(d_text, n)  # warm-up (workspace, RCCL channels)
-            ixs.close()
-            barrier()
-            t0 = time.perf_counter()
-            ixs, how = G.build_index_sharded(d_text, n)
-            barrier()
-            ts = time.perf_counter() - t0
-            same = ixs.C == ix.C and ixs.endloc == ix.endloc
-            if same:
-                probe, _ = G.gen_reads(d_text, n, 100000, m, 4242, want_offsets=False)
-                a = ix.search(probe, m, 100000, want_locrow=True)
-                b = ixs.search(probe, m, 100000, want_locrow=True)
-                same = all(torch.equal(x, y) for x, y in zip(a, b))
-            ixs.close()
-            tt = torch.tensor([ts], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            sharded = {"how": how, "wall_ms": float(tt.item()) * 1e3, "value": n / float(tt.item()) / 1e6,
-                       "unit": "Mbp/s", "same_as_whole_build": bool(same),
-                       "what": "text replicated, one bucket range of the SA sorted per rank, shards broadcast "
-                               "over RCCL, every rank finishes its own index"}
-        except Exception as e:  # noqa: BLE001 - the search figures below do not depend on this
-            sharded = {"error": f"{type(e).__name__}: {e}"[:400]}
-    else:
+    if dist is None:
         # one GPU: the eight shards of an 8-rank build, one after the other
         try:
             from bwt_amd import dist as D
@@ -221,7 +203,7 @@ def main():
     elapsed = time.perf_counter() - t0
     search_kernels = G.timing_report()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -239,9 +221,43 @@ def main():
     pos, _, locate_s, loc_ms = time_locate()
     located = int((pos != -1).sum().item())
 
+    def sharded_build():
+        """HP1 sharded: one shard of the suffix array per rank, broadcast into place."""
+        try:
+            ixs, how = G.build_index_sharded(d_text, n)  # warm-up (workspace, RCCL channels)
+            ixs.close()
+            barrier()
+            t0 = time.perf_counter()
+            ixs, how = G.build_index_sharded(d_text, n)
+            barrier()
+            ts = time.perf_counter() - t0
+            same = ixs.C == ix.C and ixs.endloc == ix.endloc
+            if same:
+                probe, _ = G.gen_reads(d_text, n, 100000, m, 4242, want_offsets=False)
+                a = ix.search(probe, m, 100000, want_locrow=True)
+                b = ixs.search(probe, m, 100000, want_locrow=True)
+                same = all(torch.equal(x, y) for x, y in zip(a, b))
+            ixs.close()
+            tt = torch.tensor([ts], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return {"how": how, "wall_ms": float(tt.item()) * 1e3, "value": n / float(tt.item()) / 1e6,
+                    "unit": "Mbp/s", "same_as_whole_build": bool(same),
+                    "what": "text replicated, one bucket range of the SA sorted per rank, shards broadcast "
+                            "over RCCL, every rank finishes its own index"}
+        except Exception as e:  # noqa: BLE001 - the search figures do not depend on this
+            return {"error": f"{type(e).__name__}: {e}"[:400]}
+
+    import threading
+    printed = threading.Lock()
+
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        # a collective that never returns must not keep this rank alive for ever
+        dog = threading.Timer(args.sharded_timeout, lambda: os._exit(0))
+        dog.daemon = True
+        dog.start()
+        sharded_build()
+        dog.cancel()
+        dist.destroy_process_group()
         return
 
     n_launch, ms_total = search_kernels.get("fm_search", (0, 0.0))
@@ -353,6 +369,23 @@ def main():
         gs = G.to_numpy_u32(sp[: args.cpu_reads])
         ge = G.to_numpy_u32(ep[: args.cpu_reads])
         result["cpu_baseline"] = cpu_baseline(args, d_text, n, d_reads, R, m, gs, ge)
+    if dist is not None:
+        # the sharded build comes last, on a timer: if one of its collectives never
+        # returns, the line goes out without it
+        def give_up():
+            if printed.acquire(blocking=False):
+                result["sa_build_sharded"] = {"error": f"no result within {args.sharded_timeout} s"}
+                print(json.dumps(result), flush=True)
+                os._exit(0)
+
+        dog = threading.Timer(args.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        out = sharded_build()
+        dog.cancel()
+        if not printed.acquire(blocking=False):
+            return  # the timer is printing
+        result["sa_build_sharded"] = out
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()

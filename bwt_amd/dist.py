@@ -21,6 +21,22 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(group):
+    """gloo moves host memory; device tensors are staged through the host for it
+    (RCCL takes them as they are)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _broadcast(t, src, group):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        if dist.get_rank() != src:
+            t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 def slice_bounds(total, world, rank):
     """Contiguous, balanced slice [lo, hi) of `total` items for `rank`."""
     base, extra = divmod(int(total), int(world))
@@ -75,7 +91,7 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
     begin, rows = rows_of[rank]
     # needs-whole-text ranks, endloc, rows built, failed ranks: every rank reaches
     # the all-reduce whatever happened to its shard, so that no peer waits forever
-    status = torch.zeros(4, dtype=torch.int64, device=sa.device)
+    status = torch.zeros(4, dtype=torch.int64, device="cpu" if _host_staged(group) else sa.device)
     failure = None
     if rows:
         try:
@@ -102,8 +118,8 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
     for g, (b, r) in enumerate(rows_of):
         if r:
             src = dist.get_global_rank(group, g) if group is not None else g
-            dist.broadcast(sa[b:b + r], src=src, group=group)
-            dist.broadcast(bw[b:b + r], src=src, group=group)
+            _broadcast(sa[b:b + r], src, group)
+            _broadcast(bw[b:b + r], src, group)
     return int(status[1])
 
 
@@ -127,6 +143,6 @@ def search_sharded(R, search_slice, gather_to=None, group=None):
                 if g == rank:
                     full[glo:ghi] = t
                 src = dist.get_global_rank(group, g) if group is not None else g
-                dist.broadcast(full[glo:ghi], src=src, group=group)
+                _broadcast(full[glo:ghi], src, group)
         out.append(full if rank == gather_to else None)
     return tuple(out)
