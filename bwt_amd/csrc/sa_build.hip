@@ -479,7 +479,7 @@ __device__ __forceinline__ void leaf_load_sort(const uint32_t *__restrict__ tb,
   for (int m = 0; m < E; ++m) lds[pad(t * E + m)] = r[m];
 }
 
-constexpr uint32_t kLeafBuckets = 4096;   // LDS buckets of the interpolation sort
+constexpr uint32_t kLeafBuckets = 2048;   // LDS buckets of the interpolation sort (16-bit counters, two per word)
 constexpr uint32_t kLeafBucketMax = 32;   // a fuller bucket sends the leaf to the bitonic network
 
 // Sorts a leaf whose keys are spread evenly (any text without long repeats):
@@ -510,7 +510,7 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
     }
   }
 #pragma unroll
-  for (int q = 0; q < (int)(kLeafBuckets / 256); ++q) cnt[q * 256 + t] = 0;
+  for (int q = 0; q < (int)(kLeafBuckets / 512); ++q) cnt[q * 256 + t] = 0;
   for (int off = 32; off; off >>= 1) {
     const uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
     kmin = a < kmin ? a : kmin;
@@ -534,16 +534,17 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
       uint32_t b = (uint32_t)((float)(word_key(r[m]) - kmin) * scale);
       b = b < kLeafBuckets ? b : kLeafBuckets - 1;
       bucket[m] = b;
-      slot[m] = atomicAdd(&cnt[b], 1u);
+      const uint32_t sh = 16u * (b & 1u);
+      slot[m] = (atomicAdd(&cnt[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
     }
   }
   __syncthreads();
-  // exclusive scan of the bucket counts; thread t owns buckets [16 t, 16 t + 16)
+  // exclusive scan of the bucket counts; thread t owns buckets [B t, B t + B)
   constexpr int B = kLeafBuckets / 256;
   uint32_t own[B], sum = 0, fullest = 0;
 #pragma unroll
   for (int q = 0; q < B; ++q) {
-    own[q] = cnt[t * B + q];
+    own[q] = (cnt[(t * B + q) >> 1] >> (16 * (q & 1))) & 0xFFFFu;
     sum += own[q];
     fullest = own[q] > fullest ? own[q] : fullest;
   }
@@ -569,16 +570,16 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
   {
     uint32_t run = first;
 #pragma unroll
-    for (int q = 0; q < B; ++q) {
-      cnt[t * B + q] = run;
-      run += own[q];
+    for (int q = 0; q < B; q += 2) {
+      cnt[(t * B + q) >> 1] = run | ((run + own[q]) << 16);  // start rows of the two buckets (< 65536)
+      run += own[q] + own[q + 1];
     }
   }
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < E; ++m) {
     const uint32_t j = (uint32_t)m * 256 + t;
-    if (j < size) lds[pad(cnt[bucket[m]] + slot[m])] = r[m];
+    if (j < size) lds[pad(((cnt[bucket[m] >> 1] >> (16 * (bucket[m] & 1u))) & 0xFFFFu) + slot[m])] = r[m];
   }
   __syncthreads();
   {
@@ -621,7 +622,7 @@ __device__ __forceinline__ int deep_cmp(const uint32_t *__restrict__ tb, uint32_
 // descending), settles short runs of equal keys by comparing the suffixes
 // further, writes the rows of the suffix array, and records for every row the
 // first row of its tie group (its own row when resolved).
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
             const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
@@ -631,7 +632,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
   __shared__ uint32_t wred[4], wmax[4];
-  __shared__ uint32_t bcnt[kLeafBuckets], bred[8];
+  __shared__ uint32_t bcnt[kLeafBuckets / 2], bred[8];
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
@@ -683,34 +684,56 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   // blocked from here on: thread t owns rows [t*per, t*per+per)
   const uint32_t per = (P + 255) / 256;  // 1..16
   const uint32_t j0 = t * per;
-  // short runs of equal keys: the thread that owns the first row of a run
-  // orders the whole run by comparing the suffixes beyond the key
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t j = j0 + k;
-    if (j + 1 >= size) break;
-    const uint32_t key = word_key(keys[pad(j)]);
-    if (word_key(keys[pad(j + 1)]) != key) continue;
-    if (j > 0 && word_key(keys[pad(j - 1)]) == key) continue;
-    uint32_t e = j + 2;
-    while (e < size && e - j <= kDeepRun && word_key(keys[pad(e)]) == key) ++e;
-    if (e - j > kDeepRun) continue;
-    bool ok = true;
-    for (uint32_t a = j + 1; a < e && ok; ++a) {
-      const uint64_t v = keys[pad(a)];
-      uint32_t b = a;
-      while (b > j) {
-        const int c = deep_cmp(tb, n, word_id(v), word_id(keys[pad(b - 1)]), depth + kLeafKeyBases);
-        if (c == 0) ok = false;
-        if (c >= 0) break;
-        keys[pad(b)] = keys[pad(b - 1)];
-        --b;
-      }
-      keys[pad(b)] = v;
+  // the thread's rows and one neighbour on each side, in registers: w[1 + k] is
+  // row j0 + k
+  uint64_t w[18];
+  auto load_window = [&]() {
+#pragma unroll
+    for (uint32_t k = 0; k < 18; ++k) {
+      const uint32_t j = j0 + k - 1u;  // wraps below row 0, which then fails j < size
+      w[k] = (k <= per + 1 && j < size) ? keys[pad(j)] : ~0ull;
     }
-    if (ok)
-      for (uint32_t a = j + 1; a < e; ++a) atomicOr(&settled[a >> 5], 1u << (a & 31u));
+  };
+  load_window();
+  bool any_equal = false;
+#pragma unroll
+  for (uint32_t k = 0; k < 17; ++k) {
+    const uint32_t j = j0 + k - 1u;  // rows j and j + 1
+    any_equal = any_equal || (k <= per && j < size && j + 1 < size && word_key(w[k]) == word_key(w[k + 1]));
   }
-  __syncthreads();
+  // equal keys are rare (none in most leaves of a random text): only then are
+  // runs settled by deeper comparison, in LDS, and the window read again
+  if (__syncthreads_or(any_equal)) {
+    // short runs of equal keys: the thread that owns the first row of a run
+    // orders the whole run by comparing the suffixes beyond the key
+    for (uint32_t k = 0; k < per; ++k) {
+      const uint32_t j = j0 + k;
+      if (j + 1 >= size) break;
+      const uint32_t key = word_key(keys[pad(j)]);
+      if (word_key(keys[pad(j + 1)]) != key) continue;
+      if (j > 0 && word_key(keys[pad(j - 1)]) == key) continue;
+      uint32_t e = j + 2;
+      while (e < size && e - j <= kDeepRun && word_key(keys[pad(e)]) == key) ++e;
+      if (e - j > kDeepRun) continue;
+      bool ok = true;
+      for (uint32_t a = j + 1; a < e && ok; ++a) {
+        const uint64_t v = keys[pad(a)];
+        uint32_t b = a;
+        while (b > j) {
+          const int c = deep_cmp(tb, n, word_id(v), word_id(keys[pad(b - 1)]), depth + kLeafKeyBases);
+          if (c == 0) ok = false;
+          if (c >= 0) break;
+          keys[pad(b)] = keys[pad(b - 1)];
+          --b;
+        }
+        keys[pad(b)] = v;
+      }
+      if (ok)
+        for (uint32_t a = j + 1; a < e; ++a) atomicOr(&settled[a >> 5], 1u << (a & 31u));
+    }
+    __syncthreads();
+    load_window();
+  }
   uint32_t hv[16];
   uint32_t local_max = 0, tied_rows = 0;
 #pragma unroll
@@ -719,9 +742,9 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     const uint32_t j = j0 + k;
     if (k < per && j < size) {
       bool tie = false, tie_next = false;
-      const uint64_t cur = keys[pad(j)];
+      const uint64_t cur = w[k + 1];
       if (j > 0) {
-        const uint64_t prv = keys[pad(j - 1)];
+        const uint64_t prv = w[k];
         const uint32_t pid = word_id(prv);
         // the previous suffix is final here if its key window ran past the
         // end of the text: a shorter suffix precedes every longer one it ties
@@ -729,7 +752,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
               (uint64_t)pid + depth + kLeafKeyBases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
       }
       if (j + 1 < size) {
-        const uint64_t nxt = keys[pad(j + 1)];
+        const uint64_t nxt = w[k + 2];
         const uint32_t cid = word_id(cur);
         tie_next = word_key(nxt) == word_key(cur) &&
                    (uint64_t)cid + depth + kLeafKeyBases < n &&
@@ -753,7 +776,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   if (lane == 0) wred[wave] = tr;
   __syncthreads();
   uint32_t before = 0;  // max over all earlier threads
-  for (uint32_t w = 0; w < wave; ++w) before = wmax[w] > before ? wmax[w] : before;
+  for (uint32_t q = 0; q < wave; ++q) before = wmax[q] > before ? wmax[q] : before;
   const uint32_t up = __shfl_up(v, 1, 64);
   if (lane) before = up > before ? up : before;
   if (t == 0) {
@@ -770,11 +793,11 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   for (uint32_t k = 0; k < 16; ++k) {
     const uint32_t j = j0 + k;
     if (k < per && j < size) {
-      const uint64_t w = keys[pad(j)];
-      const uint32_t id = word_id(w);
+      const uint64_t cur = w[k + 1];
+      const uint32_t id = word_id(cur);
       run = hv[k] > run ? hv[k] : run;
       // head row relative to the leaf (12 bits), BWT symbol, id: one word per row
-      outv[k] = ((uint64_t)(w & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
+      outv[k] = ((uint64_t)(cur & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
       if (id == 0) ctr->endloc = 1 + start + j;
     }
   }
