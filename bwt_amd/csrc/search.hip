@@ -1,10 +1,13 @@
 // FM-index backward search and locate: one read per lane, index resident in HBM.
 //
-// Per read of m bases the search makes 2(m-1) rank queries, each one 16-byte
-// load from the per-symbol layout (the two ends of an interval share the load
-// once the interval is narrow), and reads its own m/4 bytes of packed pattern;
-// locate adds one 32-byte block per LF step.  Both kernels are bound by the
-// rate of random small reads (vector L1 lookups, then L2 / Infinity Cache / HBM).
+// On rank blocks alone a read of m bases makes 2(m-1) rank queries, each one
+// 16-byte load from the per-symbol layout (the two ends of an interval share
+// the load once the interval is narrow), and locate walks LF steps of one
+// 32-byte block each.  An index that also holds the k-mer interval table skips
+// the first k steps with one 8-byte lookup; one that holds the suffix array, its
+// inverse and the text finishes from the text once a single row is left and
+// locates with one lookup.  Every form is bound by the rate of random cache-line
+// fetches, so what these shortcuts buy is fewer lines per read, not fewer bytes.
 #include "common.hpp"
 #include "fm_device.hpp"
 
