@@ -61,6 +61,8 @@ SIGNATURES = {
     "bwtgpu_index_build_from_sa": (vp, [vp, u32, vp, vp, u32, vp]),
     "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
     "bwtgpu_index_compact": (C.c_int, [vp]),
+    "bwtgpu_index_attach_text": (C.c_int, [vp, vp, vp]),
+    "bwtgpu_index_attach_text_dev": (C.c_int, [vp, vp, vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),
     "bwtgpu_locate_rows": (C.c_int, [vp, vp, u64, vp, vp, vp, sz, vp]),
     "bwtgpu_gen_genome": (C.c_int, [vp, u64, u64, vp]),

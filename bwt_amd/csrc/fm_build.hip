@@ -71,6 +71,27 @@ k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__
   }
 }
 
+// Do the bit-planes that (text, SA) give equal the ones the index holds?
+// Same work as k_emit_planes, compared instead of stored.
+__global__ void __launch_bounds__(256)
+k_check_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa, uint32_t n,
+               const uint32_t *__restrict__ d_endloc, const IndexBlock *__restrict__ blocks,
+               uint64_t nblocks, uint32_t *__restrict__ mismatch) {
+  const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63u;
+  if (b >= nblocks) return;  // wave-uniform
+  const uint32_t endloc = *d_endloc;
+  const uint64_t p = b * 64 + lane;
+  uint32_t base = 0;
+  if (p < n) {
+    const uint64_t row = p + (p >= endloc ? 1 : 0);
+    base = text_base(text, (uint64_t)sa[row] - 1);
+  }
+  const uint64_t lo = __ballot(base & 1u);
+  const uint64_t hi = __ballot(base & 2u);
+  if (lane == 0 && (blocks[b].lo != lo || blocks[b].hi != hi)) *mismatch = 1u;
+}
+
 __global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
                              uint32_t *__restrict__ isa) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,6 +473,81 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     return nullptr;
   }
   return ix;
+}
+
+int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !d_text) return set_error(kErrArg, "null argument");
+  if (ix->d_sa) return kOk;  // already there
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint32_t n = ix->n;
+  const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  hipError_t ea = pool_alloc(&ix->d_sa, rows * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, rows * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
+  auto drop = [&]() {
+    (void)hipDeviceSynchronize();
+    pool_free(ix->d_sa);
+    pool_free(ix->d_isa);
+    pool_free(ix->d_text2);
+    ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+  };
+  if (ea != hipSuccess) {
+    (void)hipGetLastError();
+    drop();
+    return set_error(kErrHip, "no room for the suffix array of %u bases: %s", n, hipGetErrorString(ea));
+  }
+  const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
+  int rc = cache_reserve(256, ws_bytes);
+  if (rc == kOk) rc = sa_build_impl(d_text, n, ix->d_sa, g_cache.ws, ws_bytes, s, nullptr);
+  if (rc == kOk) {
+    // the suffix array of this text must give the BWT the index was loaded with
+    uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
+    uint32_t *d_flag = d_endloc + 1;
+    uint32_t h[2] = {0xFFFFFFFFu, 1u};
+    hipError_t e = hipMemsetAsync(d_endloc, 0xFF, 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, s);
+    if (e == hipSuccess) {
+      BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, ix->d_sa,
+                 rows, d_endloc);
+      BWT_LAUNCH("check_planes", k_check_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0, s,
+                 d_text, ix->d_sa, n, d_endloc, ix->d_blocks, ix->nblocks, d_flag);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_endloc, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = set_error(kErrHip, "text check: %s", hipGetErrorString(e));
+    else if (h[0] != ix->endloc || h[1] != 0)
+      rc = set_error(kErrArg, "this text is not the one the index was built from");
+  }
+  if (rc == kOk) {
+    rc = inverse_suffix_array(ix->d_sa, n, ix->d_isa, sa_workspace_free_region(n, g_cache.ws), s);
+    if (rc == kOk) {
+      BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
+                 t2words, ix->d_text2);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        rc = set_error(kErrHip, "attaching the text failed");
+    }
+  }
+  if (rc != kOk) drop();
+  return rc;
+}
+
+int bwtgpu_index_attach_text(bwtgpu_index *ix, const uint8_t *h_text, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !h_text) return set_error(kErrArg, "null argument");
+  if (ix->d_sa) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  const size_t nbytes = (size_t)ix->n / 4 + 1;
+  uint8_t *d_text = nullptr;
+  BWT_HIP(hipMalloc(&d_text, nbytes + 64));
+  int rc = kOk;
+  if (hipMemcpyAsync(d_text, h_text, nbytes, hipMemcpyHostToDevice, s) != hipSuccess)
+    rc = set_error(kErrHip, "text upload failed");
+  if (rc == kOk) rc = bwtgpu_index_attach_text_dev(ix, d_text, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(d_text);
+  return rc;
 }
 
 bwtgpu_index *bwtgpu_index_build_dev(const uint8_t *d_text, uint32_t n, void *stream) {

@@ -8,7 +8,8 @@
  *   - all reads of the file go to the device in one batch, the per-read loop
  *     of search_reads.c:115-153 runs one read per lane.
  * The sequence file is not needed to search (read_index ignores it, as in the
- * reference); it is still opened so a wrong path fails the same way.
+ * reference); it is packed as build_index packs it and handed to the device,
+ * which uses it to speed the searches up when it is the text of the index.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,15 +27,28 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Could not open sequence\n");
     exit(-1);
   }
+  fseek(sfp, 0L, SEEK_END);
+  long slen = ftell(sfp);
+  rewind(sfp);
+  char *ascii = malloc(slen + 1), *seq = malloc(slen / 4 + 1);
+  if (ascii && seq && fread(ascii, 1, slen, sfp) == (size_t)slen) {
+    fmi_pack_ascii(ascii, slen, seq);
+  } else {
+    free(seq);
+    seq = NULL;
+  }
+  free(ascii);
   fclose(sfp);
   FILE *ifp = fopen(argv[2], "rb");
   if (!ifp) {
     fprintf(stderr, "Could not open index file");
     exit(-1);
   }
-  fm_index *fmi = read_index(NULL, ifp);
+  fm_index *fmi = read_index(seq, ifp);
   fclose(ifp);
   if (!fmi) return 1;
+  if (seq && fmi->len == (int)slen) fmi_attach_text(fmi, seq); /* a text that does not fit is left out */
+  free(seq);
   FILE *rfp = fopen(argv[3], "r");
   if (!rfp) {
     fprintf(stderr, "Could not open reads file");

@@ -148,6 +148,17 @@ class GpuIndex:
                 "pattern_words_4B": pat, "kmer_entries_8B": kmr,
                 "bytes": 16 * blk + 8 * txt + 4 * ent + 4 * pat + 8 * kmr}, sp, ep
 
+    def attach_text(self, text):
+        """Give an index loaded from its stored parts the text it was built from
+        (numpy on the host or a CUDA tensor); see bwtgpu_index_attach_text."""
+        lib = _lib.load()
+        if isinstance(text, torch.Tensor):
+            check(lib.bwtgpu_index_attach_text_dev(self.h, _ptr(text), _stream()))
+        else:
+            text = np.ascontiguousarray(text, np.uint8)
+            assert len(text) >= self.n // 4 + 1
+            check(lib.bwtgpu_index_attach_text(self.h, text.ctypes.data_as(C.c_void_p), _stream()))
+
     def compact(self):
         """Drop the kept suffix array, its inverse and the text (see bwtgpu_index_compact)."""
         check(_lib.load().bwtgpu_index_compact(self.h))

@@ -520,6 +520,16 @@ void fmi_encode_read(const char *ascii, long len, char *out) {
 /* genome packer                                                       */
 /* ------------------------------------------------------------------ */
 
+int fmi_attach_text(const fm_index *fmi, const char *seq) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix || !seq) return -1;
+  if (bwtgpu_index_attach_text(ix, (const uint8_t *)seq, NULL)) {
+    report("attach text");
+    return -1;
+  }
+  return 0;
+}
+
 void fmi_pack_ascii(const char *ascii, long len, char *out) {
   /* build_index.c:54-77: exact-case C, G, T; everything else, and everything
    * past the end of the file, is A */

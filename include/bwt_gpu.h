@@ -107,6 +107,14 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n,
 bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n,
                                       uint32_t endloc, const uint32_t *h_idxs,
                                       void *stream);
+/* read_index (fileio.c:24-65) is handed the text the index was built from and
+ * ignores it.  Here the text can be put to use: these calls rebuild the
+ * suffix array from it on the device, check that it gives the BWT and $ row
+ * the index holds (-2 and nothing changed if not), and leave the index as one
+ * built from the text (suffix array, inverse, text copy; see
+ * bwtgpu_index_compact).  Results of searches do not change, their speed does. */
+int bwtgpu_index_attach_text(bwtgpu_index *ix, const uint8_t *h_text, void *stream);
+int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *stream);
 void bwtgpu_index_free(bwtgpu_index *ix);
 /* The fields of fm_index (seqindex.h:14-22) that write_index stores
  * (fileio.c:11-15).  Any output pointer may be NULL. */

@@ -100,6 +100,12 @@ int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, l
  * anchors, last forward position, last backward position (-1: none). */
 int fmi_search_reads_batch(const fm_index *fmi, const char *reads, const unsigned long *offsets,
                            long nreads, int anchor, int *out);
+/* read_index (fileio.c:24) ignores the sequence it is given.  This call hands
+ * the packed sequence the index was built from to the device, which checks it
+ * against the index and then uses it to speed up searches and locate (same
+ * results).  Returns 0, or -1 with the index unchanged (wrong text, no memory). */
+int fmi_attach_text(const fm_index *fmi, const char *seq);
+
 /* ASCII -> symbols as single_align.c:450-474 encodes reads: A C G T -> 0 1 2 3,
  * anything else -> 5 */
 void fmi_encode_read(const char *ascii, long len, char *out);
