@@ -40,8 +40,10 @@ struct Seg {
   uint32_t start, size;  // rows [start, start+size) of SA+1 (row 0 of the SA is the $ suffix)
 };
 struct Leaf {
-  uint32_t start, size, depth, src;
+  uint32_t start, size, depth;
+  uint32_t src;  // low byte: kSrcA / kSrcB / kSrcImplicit; next byte: bases of text in the stored sort keys
 };
+__host__ __device__ inline uint32_t leaf_src_word(uint32_t src, uint32_t keybases) { return src | (keybases << 8); }
 
 struct Counters {
   uint32_t nnext;       // segments emitted for the next level
@@ -88,10 +90,18 @@ __device__ __forceinline__ uint32_t base_before(const uint32_t *__restrict__ tb,
   return (tb[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u;
 }
 
-// What travels with a suffix id from the scatter to the leaf sort: the 15
-// bases after the bucket prefix (the sort key) and, in the low two bits, the
-// base that precedes the suffix (its BWT symbol), both read from the same
-// line of text while the scatter has it in hand.
+// What travels with a suffix id from the scatter to the leaf sort: 15 bases of
+// the suffix (sort key and the digits of further levels) and, in the low two
+// bits, the base that precedes the suffix (its BWT symbol), both read from the
+// same line of text while the scatter has it in hand.
+//
+// Where the 15 bases start: level 0 reads the text in order and so can look
+// ahead for free; a suffix going on to level 1 gets bases 4..18 (its level-0
+// digit is implied by its bucket), one that ends in a level-0 leaf bases 0..14.
+// Level 1 finds its digit in the top byte and passes the word on unchanged;
+// from level 2 on the digit is the second byte and the word moves up one byte
+// per level.  A word therefore serves two levels after level 0 before the text
+// has to be gathered from again, and leaves sort by 15 or 11 bases of text.
 __device__ __forceinline__ uint32_t carried_word(const uint32_t *__restrict__ tb, uint32_t id,
                                                  uint32_t key) {
   return (key & ~3u) | (id ? base_before(tb, id) : 0u);
@@ -146,7 +156,9 @@ constexpr uint32_t kHistTilesPerGroup = 8;
 // MODE 0: ids are implicit (level 0: the tile is a range of text positions);
 // MODE 1: ids from src, bases from the text;
 // MODE 2: the bases are bits 23..16 of the word the previous level's scatter
-//         stored next to the id (its key started four bases earlier): no gather.
+//         stored next to the id (its key started four bases earlier): no gather;
+// MODE 3: the bases are the top byte of that word (level 1: level 0 stored
+//         words that start at this level's depth).
 template <int MODE>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
@@ -178,6 +190,8 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
         uint32_t d;
         if (MODE == 2) {
           d = (srckey[row0 + j] >> 16) & 255u;
+        } else if (MODE == 3) {
+          d = srckey[row0 + j] >> 24;
         } else {
           const uint32_t id = MODE == 0 ? row0 + j : src[row0 + j];
           d = key32(tb, (uint64_t)id + depth) >> 24;
@@ -199,7 +213,7 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
 // depth, so the bases that separate the merged children are part of its key).
 __global__ void __launch_bounds__(256)
 k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
-                uint32_t dst_id, Seg *__restrict__ next_segs, uint32_t next_cap,
+                uint32_t dst_id /* leaf_src_word */, Seg *__restrict__ next_segs, uint32_t next_cap,
                 Leaf *__restrict__ leaves, uint32_t leaf_cap, uint32_t *__restrict__ leafmask,
                 Counters *__restrict__ ctr) {
   __shared__ uint32_t sizes[256], starts[256], wsum[4];
@@ -290,9 +304,8 @@ k_restrict_level0(uint32_t *__restrict__ counts, uint32_t dlo, uint32_t dhi,
 // inside a bucket is irrelevant at this stage.
 // IMPLICIT (level 0): ids are text positions, keys come from sequential text.
 // Otherwise the bucket of a suffix is read from the word the previous level
-// stored with it; a fresh 16-base key is gathered from the text only for
-// suffixes whose bucket ends in a leaf (or for all when the stored words have
-// been shifted twice already and hold no further level's bases).
+// stored with it, and the word is passed on; fresh keys are gathered from the
+// text only when the stored words have run out of bases (see carried_word).
 template <bool IMPLICIT>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
@@ -300,7 +313,10 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
                const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
                const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors,
-               const uint32_t *__restrict__ leafmask, int gather_all, uint32_t dlo, uint32_t dhi) {
+               const uint32_t *__restrict__ leafmask, int gather_all, int top_digit, uint32_t dlo,
+               uint32_t dhi) {
+  // gather_all: the stored words have run out of bases, read fresh ones for every suffix.
+  // top_digit: the source word starts at this level's depth (level 1).
   // dlo, dhi (level 0 only): suffixes whose first digit lies outside [dlo, dhi)
   // belong to another shard of the build and are dropped here
   __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4], lmask[8];
@@ -312,8 +328,8 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   fill[t] = 0;
   if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
-  if (!IMPLICIT) {
-    if (t < 8) lmask[t] = gather_all ? 0xFFFFFFFFu : leafmask[(uint64_t)ti.seg * 8 + t];
+  if (IMPLICIT) {
+    if (t < 8) lmask[t] = leafmask[(uint64_t)ti.seg * 8 + t];
     __syncthreads();
   }
   uint32_t id[kPartItems], key[kPartItems];
@@ -329,17 +345,19 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
         if (d < dlo || d >= dhi) continue;
         mine |= 1u << i;
         atomicAdd(&hist[d], 1u);
-        key[i] = carried_word(tb, id[i], k32);
+        const bool leaf = (lmask[d >> 5] >> (d & 31u)) & 1u;
+        key[i] = carried_word(tb, id[i], leaf ? k32 : key32(tb, (uint64_t)id[i] + kDigitBases));
+        id[i] = (d << 24) | j;  // the digit rides with the tile-local index: the word may not start with it
       } else {
         mine |= 1u << i;
         id[i] = src[row0 + j];
         const uint32_t old = srckey[row0 + j];
-        const uint32_t d = (old >> 16) & 255u;
+        const uint32_t d = top_digit ? old >> 24 : (old >> 16) & 255u;
         atomicAdd(&hist[d], 1u);
-        if ((lmask[d >> 5] >> (d & 31u)) & 1u)
+        if (gather_all)
           key[i] = (key32(tb, (uint64_t)id[i] + depth) & ~3u) | (old & 3u);
         else
-          key[i] = ((old & ~3u) << 8) | (old & 3u);
+          key[i] = top_digit ? old : ((old & ~3u) << 8) | (old & 3u);
       }
     }
   }
@@ -362,7 +380,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
     if ((mine >> i) & 1u) {
-      const uint32_t d = key[i] >> 24;
+      const uint32_t d = IMPLICIT ? id[i] >> 24 : key[i] >> 24;
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
       kv[p] = key[i];
@@ -371,9 +389,10 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
   for (uint32_t j = t; j < placed; j += kPartThreads) {
-    const uint32_t k = kv[j], d = k >> 24;
+    const uint32_t k = kv[j], v = ids[j];
+    const uint32_t d = IMPLICIT ? v >> 24 : k >> 24;
     const uint32_t pos = gbase[d] + (j - lstart[d]);
-    dst[pos] = ids[j];
+    dst[pos] = IMPLICIT ? row0 + (v & 0xFFFFFFu) : v;
     dstkey[pos] = k;
   }
 }
@@ -635,8 +654,9 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   __shared__ uint32_t bcnt[kLeafBuckets / 2], bred[8];
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
-  const uint32_t *src = lf.src == kSrcA ? bufA : lf.src == kSrcB ? bufB : nullptr;
-  const uint32_t *srckey = lf.src == kSrcA ? keyA : keyB;
+  const uint32_t srcid = lf.src & 255u, keybases = lf.src >> 8;
+  const uint32_t *src = srcid == kSrcA ? bufA : srcid == kSrcB ? bufB : nullptr;
+  const uint32_t *srckey = srcid == kSrcA ? keyA : keyB;
   if (size == 1) {
     if (t == 0) {
       const uint64_t w = leaf_fetch(tb, src, srckey, start, depth);
@@ -720,7 +740,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
         const uint64_t v = keys[pad(a)];
         uint32_t b = a;
         while (b > j) {
-          const int c = deep_cmp(tb, n, word_id(v), word_id(keys[pad(b - 1)]), depth + kLeafKeyBases);
+          const int c = deep_cmp(tb, n, word_id(v), word_id(keys[pad(b - 1)]), depth + keybases);
           if (c == 0) ok = false;
           if (c >= 0) break;
           keys[pad(b)] = keys[pad(b - 1)];
@@ -749,13 +769,13 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
         // the previous suffix is final here if its key window ran past the
         // end of the text: a shorter suffix precedes every longer one it ties
         tie = word_key(prv) == word_key(cur) &&
-              (uint64_t)pid + depth + kLeafKeyBases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
+              (uint64_t)pid + depth + keybases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
       }
       if (j + 1 < size) {
         const uint64_t nxt = w[k + 2];
         const uint32_t cid = word_id(cur);
         tie_next = word_key(nxt) == word_key(cur) &&
-                   (uint64_t)cid + depth + kLeafKeyBases < n &&
+                   (uint64_t)cid + depth + keybases < n &&
                    !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
       }
       hv[k] = tie ? 0u : 1u + start + j;
@@ -783,7 +803,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     const uint32_t total = wred[0] + wred[1] + wred[2] + wred[3];
     if (total) {
       atomicAdd(&ctr->unresolved, total);
-      atomicMin(&ctr->min_depth, depth + kLeafKeyBases);
+      atomicMin(&ctr->min_depth, depth + keybases);
     }
   }
   // every thread has read its neighbours' keys; now reuse the LDS slots
@@ -1099,7 +1119,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   int cur = 0;
   uint32_t nleaves_host = 0;
   if (n <= kLeafMax) {
-    const Leaf whole = {0, n, 0, kSrcImplicit};
+    const Leaf whole = {0, n, 0, leaf_src_word(kSrcImplicit, kLeafKeyBases)};
     BWT_HIP(hipMemcpyAsync(leaves, &whole, sizeof whole, hipMemcpyHostToDevice, s));
     nleaves_host = 1;
   } else {
@@ -1108,7 +1128,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     nsegs = 1;
   }
   int levels = 0;
-  int key_age = 0;  // levels since the words stored with the ids were read from the text
+  uint32_t reach = 0;  // the words stored with the ids hold the text up to this base (exclusive)
   while (nsegs > 0 && depth < kMaxDepth) {
     const uint32_t dst_id = src_id == kSrcA ? kSrcB : kSrcA;
     const uint32_t *src = src_id == kSrcA ? bufA : src_id == kSrcB ? bufB : nullptr;
@@ -1127,11 +1147,21 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_hist", k_part_hist<0>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
                  srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+    } else if (levels == 1) {
+      // level 0 stored words that start with this level's four bases
+      BWT_LAUNCH("sa_part_hist", k_part_hist<3>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     } else {
-      // the word stored by the previous level holds this level's four bases
+      // the word stored by the previous level holds this level's four bases in its second byte
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
                  srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     }
+    // Without a gather a suffix that ends in a leaf keeps bases [depth, reach) as
+    // its sort key, and one that goes on needs the next level's digit, bases
+    // [depth + 4, depth + 8).  Level 0 always reads the text.
+    const bool implicit = src_id == kSrcImplicit;
+    const bool gather_all = !implicit && (reach < depth + 11 || reach < depth + 2 * kDigitBases);
+    const uint32_t leaf_keybases = (implicit || gather_all) ? kLeafKeyBases : reach - depth;
     if (range && depth == 0) {
       // rows of other shards leave the picture here; the scan workspace is idle
       uint64_t *d_out = reinterpret_cast<uint64_t *>(scanws);
@@ -1150,19 +1180,18 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       }
     }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
-               dst_id, segs[cur ^ 1], L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
+               leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
+               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, dlo,
+                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, 0, dlo,
                  dhi);
-      key_age = 0;
+      reach = kDigitBases + kLeafKeyBases;  // suffixes that go on carry bases 4..18
     } else {
-      // stored words shifted twice hold no bases for a further level: refresh all
-      const int gather_all = key_age >= 1;
-      BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter<false>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
-                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask,
-                 gather_all, 0u, 256u);
-      key_age = gather_all ? 0 : key_age + 1;
+      BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter<false>,
+                 dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
+                 nsegs, depth, ctr, counts, leafmask, gather_all ? 1 : 0, levels == 1 ? 1 : 0, 0u, 256u);
+      if (gather_all) reach = depth + kLeafKeyBases;
     }
     BWT_CHECK_LAUNCH();
     BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
