@@ -3,7 +3,7 @@
 // Replaces histsort (histsortcomp.c:161-180) and csuff_arr (csacak.c:521-528).
 // The reference sorts one base per level by count + scatter (histhelper,
 // histsortcomp.c:35-90).  Here a level consumes four bases (256 buckets):
-//   1. k_part_hist     LDS-privatised k-mer histogram per 4096-suffix tile,
+//   1. k_part_hist     LDS-privatised k-mer histogram per 8192-suffix tile,
 //                      merged into per-segment counters
 //   2. k_part_classify per-segment prefix sum -> child bucket cursors; children
 //                      above kLeafMax rows go to the next level, runs of small
@@ -25,9 +25,11 @@
 
 namespace bwtgpu {
 
-constexpr int kPartThreads = 256;
-constexpr int kPartItems = 16;
-constexpr int kPartTile = kPartThreads * kPartItems;  // 4096 suffixes per tile
+constexpr int kPartThreads = 256;                      // histogram workgroup
+constexpr int kScatThreads = 512;                      // scatter workgroup
+constexpr int kPartItems = 16;                         // suffixes per scatter thread
+constexpr int kPartTile = kScatThreads * kPartItems;   // 8192 suffixes per tile: 32-element runs per bucket
+constexpr int kHistItems = kPartTile / kPartThreads;
 constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
 constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
 constexpr uint32_t kMaxDepth = 24;                    // bucket levels stop here; doubling takes over
@@ -149,7 +151,7 @@ __device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *til
   return locate_tile_at(blockIdx.x, segs, tile_first, nsegs, ctr, sh);
 }
 
-constexpr uint32_t kHistTilesPerGroup = 8;
+constexpr uint32_t kHistTilesPerGroup = 4;
 
 // LDS-privatised histogram of the next four bases of every suffix in a run of
 // tiles; counts go to the segment's counters when the run leaves the segment.
@@ -184,7 +186,7 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
     if (!live) break;
     const uint32_t row0 = ti.row0, count = ti.count;
 #pragma unroll 4
-    for (int i = 0; i < kPartItems; ++i) {
+    for (int i = 0; i < kHistItems; ++i) {
       const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
       if (j < count) {
         uint32_t d;
@@ -307,7 +309,7 @@ k_restrict_level0(uint32_t *__restrict__ counts, uint32_t dlo, uint32_t dhi,
 // stored with it, and the word is passed on; fresh keys are gathered from the
 // text only when the stored words have run out of bases (see carried_word).
 template <bool IMPLICIT>
-__global__ void __launch_bounds__(kPartThreads)
+__global__ void __launch_bounds__(kScatThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
                const uint32_t *__restrict__ srckey, uint32_t *__restrict__ dst,
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
@@ -324,8 +326,10 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   __shared__ uint32_t kv[kPartTile];
   __shared__ TileInfo ti;
   const uint32_t t = threadIdx.x;
-  hist[t] = 0;
-  fill[t] = 0;
+  if (t < 256) {
+    hist[t] = 0;
+    fill[t] = 0;
+  }
   if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
   if (IMPLICIT) {
@@ -336,7 +340,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   uint32_t mine = 0;  // bit i: item i is a suffix this launch places
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    const uint32_t j = (uint32_t)i * kPartThreads + t;
+    const uint32_t j = (uint32_t)i * kScatThreads + t;
     if (j < count) {
       if (IMPLICIT) {
         id[i] = row0 + j;
@@ -362,20 +366,25 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     }
   }
   __syncthreads();
-  // exclusive scan of the 256 bucket counts; claim global room per bucket
-  const uint32_t c = hist[t];
-  uint32_t v = c;
+  // exclusive scan of the 256 bucket counts by the first four waves; claim global room per bucket
   const uint32_t lane = t & 63u, wave = t >> 6;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
+  uint32_t c = 0, v = 0;
+  if (t < 256) {
+    c = hist[t];
+    v = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
   }
-  if (lane == 63) wsum[wave] = v;
   __syncthreads();
-  uint32_t pre = 0;
-  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
-  lstart[t] = pre + v - c;
-  gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+  if (t < 256) {
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+    lstart[t] = pre + v - c;
+    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
@@ -388,7 +397,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
-  for (uint32_t j = t; j < placed; j += kPartThreads) {
+  for (uint32_t j = t; j < placed; j += kScatThreads) {
     const uint32_t k = kv[j], v = ids[j];
     const uint32_t d = IMPLICIT ? v >> 24 : k >> 24;
     const uint32_t pos = gbase[d] + (j - lstart[d]);
@@ -1183,13 +1192,13 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
                L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kPartThreads), 0, s, tb,
+      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kScatThreads), 0, s, tb,
                  src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, 0, dlo,
                  dhi);
       reach = kDigitBases + kLeafKeyBases;  // suffixes that go on carry bases 4..18
     } else {
       BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter<false>,
-                 dim3(tile_bound), dim3(kPartThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
+                 dim3(tile_bound), dim3(kScatThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
                  nsegs, depth, ctr, counts, leafmask, gather_all ? 1 : 0, levels == 1 ? 1 : 0, 0u, 256u);
       if (gather_all) reach = depth + kLeafKeyBases;
     }
