@@ -1,7 +1,9 @@
 // FM-index build on device (make_fmi, seqindex.c:161-189): suffix array, BWT
-// (sprintcbwt, histsortcomp.c:220-250), every 32nd SA row (seqindex.c:173-176),
-// rank blocks and C[] (seq_index, seqindex.c:23-87, :183-187).  The suffix
-// array stays in HBM; only what write_index stores ever goes to the host.
+// (sprintcbwt, histsortcomp.c:220-250), sampled SA rows (seqindex.c:173-176;
+// every 8th here, thinned to every 32nd on export), rank blocks and C[]
+// (seq_index, seqindex.c:23-87, :183-187), and what an index keeps beyond that:
+// the suffix array itself, its inverse, the text in words, the k-mer table.
+// Only what write_index stores ever goes to the host.
 #include <cstdlib>
 
 #include "common.hpp"

@@ -23,7 +23,7 @@ constexpr uint32_t kPackLdsBytes = 48 * 1024;
 // pattern loads are coalesced and cost m/4 bytes per read.
 __global__ void __launch_bounds__(kPackThreads)
 k_pack_reads(const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride, uint64_t R,
-             uint32_t *__restrict__ packed, uint32_t span_bytes, int use_lds) {
+             uint32_t *__restrict__ packed, int use_lds) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint64_t r0 = (uint64_t)blockIdx.x * kPackThreads;
   const uint64_t r = r0 + threadIdx.x;
@@ -63,7 +63,6 @@ k_pack_reads(const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride, uint
       packed[(uint64_t)w * R + r] = acc;
     }
   }
-  (void)span_bytes;
 }
 
 struct CTable {
@@ -353,8 +352,7 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   const uint64_t span = (uint64_t)(kPackThreads - 1) * stride + m + 16;
   const int use_lds = span <= kPackLdsBytes;
   BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),
-             use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed,
-             (uint32_t)(use_lds ? span : 0), use_lds);
+             use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
   BWT_CHECK_LAUNCH();
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
