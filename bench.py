@@ -325,6 +325,8 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": measured_traffic(f"{n}bp_{R}x{m}"),
+            # the kernel is bound by how many cache lines per second leave L2, not by bytes
+            "l2_miss_lines_per_s": (measured_traffic(f"{n}bp_{R}x{m}_l2_misses") or 0) / (k_ms * 1e-3) if k_ms else None,
             "bytes_per_read": bpr,
             "loads": loads,
             "counting_pass_matches": counted_ok,
