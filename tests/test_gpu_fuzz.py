@@ -1,0 +1,13 @@
+"""A bounded slice of the randomised differential run (tools_fuzz.py): every
+product of the build and every search form against the oracle on texts of six
+kinds, sizes 1 .. 200,000."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_randomised_texts_against_the_oracle(gpu):
+    import tools_fuzz
+
+    cases = tools_fuzz.main(budget=20.0, seed0=7000, nmax=200000, max_cases=250, quiet=True)
+    assert cases >= 50

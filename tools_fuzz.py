@@ -9,11 +9,6 @@ import numpy as np, torch
 from bwt_amd import gpu as G, synth, dist as D, _lib
 from oracle import load_oracle
 orc = load_oracle()
-G.init(0)
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-nmax = int(float(sys.argv[3])) if len(sys.argv) > 3 else 300000
-t_end = time.time() + budget
 
 def make_text(rng, n):
     kind = rng.integers(0, 6)
@@ -64,74 +59,85 @@ def mms_gpu(ix, pats):
     _lib.check(_lib.load().bwtgpu_mms(ix.h, d.data_ptr(), m, m, R, got.data_ptr(), sp.data_ptr(), ep.data_ptr(), None))
     return list(zip(got.cpu().numpy().tolist(), G.to_numpy_u32(sp).tolist(), G.to_numpy_u32(ep).tolist()))
 
-it = 0
-seed = seed0
-while time.time() < t_end:
-    rng = np.random.default_rng(seed)
-    n = int(np.exp(rng.uniform(0, np.log(nmax)))) + 1
-    kind, text, bases = make_text(rng, n)
-    label = f"seed={seed} n={n} kind={kind}"
-    try:
-        sa_o = orc.sa_doubling(text, n)
-        fo = orc.make_fmi(text, n, sa_o)
-        k_env = int(rng.integers(0, 12))
-        if rng.integers(0, 2):
-            os.environ["BWT_MI355X_KMER"] = str(k_env)
-        else:
+def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
+    G.init(0)
+    t_end = time.time() + budget
+    it = 0
+    seed = seed0
+    while time.time() < t_end and (max_cases is None or it < max_cases):
+        rng = np.random.default_rng(seed)
+        n = int(np.exp(rng.uniform(0, np.log(nmax)))) + 1
+        kind, text, bases = make_text(rng, n)
+        label = f"seed={seed} n={n} kind={kind}"
+        try:
+            sa_o = orc.sa_doubling(text, n)
+            fo = orc.make_fmi(text, n, sa_o)
+            k_env = int(rng.integers(0, 12))
+            if rng.integers(0, 2):
+                os.environ["BWT_MI355X_KMER"] = str(k_env)
+            else:
+                os.environ.pop("BWT_MI355X_KMER", None)
+            if rng.integers(0, 3) == 0:
+                os.environ["BWT_MI355X_ISA_TWO_STEP"] = "1"
+            else:
+                os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
+            t = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
+            sa = G.sa_build(t, n)
+            assert np.array_equal(G.to_numpy_u32(sa), sa_o), "SA"
+            full = G.build_index_dev(t, n)
+            lean = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+            assert full.endloc == fo.endloc and full.C == fo.C, "endloc/C"
+            bwt, idxs = full.export()
+            assert np.array_equal(bwt, fo.bwt) and np.array_equal(idxs, fo.idxs), "export"
+            assert np.array_equal(full.rank_rows16(), fo.rank_rows), "rank rows"
+            rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
+            for ix in (full, lean):
+                assert np.array_equal(G.to_numpy_u32(ix.locate_rows(rows)), sa_o), "locate"
+            # sharded
+            if n > 4096:
+                world = int(rng.integers(2, 9))
+                counts = G.sa_bucket_counts(t, n)
+                ranges = D.plan_bucket_ranges(counts, world); rows_of = D.shard_rows(counts, ranges)
+                sh = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda"); sh[0] = n
+                ok = True
+                for (lo, hi), (b, r) in zip(ranges, rows_of):
+                    if r:
+                        try:
+                            G.sa_build_range(t, n, lo, hi, sh[b:b + r])
+                        except G.BwtGpuError as e:
+                            assert e.code == -6, str(e); ok = False; break
+                if ok:
+                    assert torch.equal(sh, sa), "shards"
+            for m in sorted(set(int(x) for x in rng.integers(1, 120, 3))):
+                R = 400
+                reads = reads_for(rng, bases, n, R, m, False)
+                sp_o, ep_o = orc.search_batch(fo, reads, m, m, R)
+                want_loc = [orc.locate(fo, reads[r]) for r in range(R)]
+                d = torch.from_numpy(reads.reshape(-1)).cuda()
+                for name, ix in (("full", full), ("lean", lean)):
+                    sp, ep, lr = (G.to_numpy_u32(x) for x in ix.search(d, m, R, want_locrow=True))
+                    assert np.array_equal(sp, sp_o) and np.array_equal(ep, ep_o), f"search {name} m={m}"
+                    pos = G.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda())).astype(np.int64)
+                    pos[pos == 0xFFFFFFFF] = -1
+                    assert pos.tolist() == want_loc, f"locate() {name} m={m}"
+                readsn = reads_for(rng, bases, n, 200, m, True)
+                want = [orc.mms(fo, readsn[r]) for r in range(200)]
+                for name, ix in (("full", full), ("lean", lean)):
+                    assert mms_gpu(ix, readsn) == want, f"mms {name} m={m}"
+            full.close(); lean.close()
+        except AssertionError as e:
+            raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')}: {e}") from e
+        finally:
             os.environ.pop("BWT_MI355X_KMER", None)
-        if rng.integers(0, 3) == 0:
-            os.environ["BWT_MI355X_ISA_TWO_STEP"] = "1"
-        else:
             os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
-        t = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
-        sa = G.sa_build(t, n)
-        assert np.array_equal(G.to_numpy_u32(sa), sa_o), "SA"
-        full = G.build_index_dev(t, n)
-        lean = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
-        assert full.endloc == fo.endloc and full.C == fo.C, "endloc/C"
-        bwt, idxs = full.export()
-        assert np.array_equal(bwt, fo.bwt) and np.array_equal(idxs, fo.idxs), "export"
-        assert np.array_equal(full.rank_rows16(), fo.rank_rows), "rank rows"
-        rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
-        for ix in (full, lean):
-            assert np.array_equal(G.to_numpy_u32(ix.locate_rows(rows)), sa_o), "locate"
-        # sharded
-        if n > 4096:
-            world = int(rng.integers(2, 9))
-            counts = G.sa_bucket_counts(t, n)
-            ranges = D.plan_bucket_ranges(counts, world); rows_of = D.shard_rows(counts, ranges)
-            sh = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda"); sh[0] = n
-            ok = True
-            for (lo, hi), (b, r) in zip(ranges, rows_of):
-                if r:
-                    try:
-                        G.sa_build_range(t, n, lo, hi, sh[b:b + r])
-                    except G.BwtGpuError as e:
-                        assert e.code == -6, str(e); ok = False; break
-            if ok:
-                assert torch.equal(sh, sa), "shards"
-        for m in sorted(set(int(x) for x in rng.integers(1, 120, 3))):
-            R = 400
-            reads = reads_for(rng, bases, n, R, m, False)
-            sp_o, ep_o = orc.search_batch(fo, reads, m, m, R)
-            want_loc = [orc.locate(fo, reads[r]) for r in range(R)]
-            d = torch.from_numpy(reads.reshape(-1)).cuda()
-            for name, ix in (("full", full), ("lean", lean)):
-                sp, ep, lr = (G.to_numpy_u32(x) for x in ix.search(d, m, R, want_locrow=True))
-                assert np.array_equal(sp, sp_o) and np.array_equal(ep, ep_o), f"search {name} m={m}"
-                pos = G.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda())).astype(np.int64)
-                pos[pos == 0xFFFFFFFF] = -1
-                assert pos.tolist() == want_loc, f"locate() {name} m={m}"
-            readsn = reads_for(rng, bases, n, 200, m, True)
-            want = [orc.mms(fo, readsn[r]) for r in range(200)]
-            for name, ix in (("full", full), ("lean", lean)):
-                assert mms_gpu(ix, readsn) == want, f"mms {name} m={m}"
-        full.close(); lean.close()
-    except AssertionError as e:
-        print("MISMATCH", label, "kmer_env", os.environ.get("BWT_MI355X_KMER"), e, flush=True)
-        sys.exit(1)
-    it += 1
-    seed += 1
-    if it % 5 == 0:
-        print(f"{it} cases ok (last {label})", flush=True)
-print(f"fuzz OK: {it} cases, seeds {seed0}..{seed - 1}")
+        it += 1
+        seed += 1
+        if it % 5 == 0 and not quiet:
+            print(f"{it} cases ok (last {label})", flush=True)
+    print(f"fuzz OK: {it} cases, seeds {seed0}..{seed - 1}", flush=True)
+    return it
+
+
+if __name__ == "__main__":
+    main(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+         int(float(sys.argv[3])) if len(sys.argv) > 3 else 300000)
