@@ -100,8 +100,9 @@ __global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
   if (j < rows) isa[sa[j]] = (uint32_t)j;
 }
 
-// Inverse of a suffix array too large for the Infinity Cache, in two steps so
-// that the 4-byte scatter stays inside a window the cache holds: first the
+// Inverse of a suffix array, in two steps so that the 4-byte scatter stays
+// inside a window a cache holds (one XCD's L2 up to about 10^9 rows, the
+// Infinity Cache beyond): first the
 // (position, row) pairs are dealt into up to 256 bins by the top bits of the
 // position -- bin b owns positions [b << shift, (b+1) << shift), so its pairs
 // fill exactly that range of the pair buffer and no counting pass is needed --
@@ -158,9 +159,15 @@ k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
   }
 }
 
+// Workgroups go to the eight XCDs round-robin, and each XCD has its own L2:
+// workgroup i takes the chunk of pairs that keeps every XCD inside its own
+// eighth of the pair buffer, so the 4-byte stores into one window meet in one L2
+// and leave it as whole lines.
 __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
                            uint32_t *__restrict__ isa) {
-  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+  const uint64_t chunk = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint64_t j = chunk * blockDim.x + threadIdx.x;
   if (j >= rows) return;
   const uint64_t pr = pairs[j];
   isa[(uint32_t)pr] = (uint32_t)(pr >> 32);
@@ -171,9 +178,9 @@ __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
 static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_isa, void *scratch,
                                 hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1;
-  // up to 2^26 entries the array is cache-resident and one scatter is fastest
+  // small arrays sit in L2 whatever the order of the stores
   const bool force = getenv("BWT_MI355X_ISA_TWO_STEP") != nullptr;  // for tests on small texts
-  if (!scratch || (rows <= (1ull << 26) && !force)) {
+  if (!scratch || (rows <= (1ull << 22) && !force)) {
     BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa);
     return kOk;
   }
@@ -187,7 +194,9 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   BWT_HIP(hipStreamSynchronize(s));  // h_cur leaves the stack
   BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
              rows, shift, d_cur, pairs);
-  BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, pairs, rows, d_isa);
+  // a multiple of eight workgroups, so that every XCD gets the same number of chunks
+  BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, pairs,
+             rows, d_isa);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
@@ -463,7 +472,7 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
   if (rc == kOk && d_bw && hipMemcpyAsync(d_endloc, &endloc, 4, hipMemcpyHostToDevice, s) != hipSuccess)
     rc = set_error(kErrHip, "endloc upload failed");
   void *scratch = nullptr;
-  if (rc == kOk && ix->d_sa && (uint64_t)n + 1 > (1ull << 26) &&
+  if (rc == kOk && ix->d_sa && (uint64_t)n + 1 > (1ull << 22) &&
       hipMalloc(&scratch, ((size_t)n + 1) * 8 + 2048) != hipSuccess) {
     (void)hipGetLastError();
     scratch = nullptr;  // the one-step scatter needs none
