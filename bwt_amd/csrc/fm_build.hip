@@ -163,10 +163,14 @@ k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
 // workgroup i takes the chunk of pairs that keeps every XCD inside its own
 // eighth of the pair buffer, so the 4-byte stores into one window meet in one L2
 // and leave it as whole lines.
+// That pays while a window fits an L2 (xcd_local); larger windows live in the
+// Infinity Cache, which all XCDs share, and are then filled one after the other
+// by all of them.
 __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
-                           uint32_t *__restrict__ isa) {
+                           uint32_t *__restrict__ isa, int xcd_local) {
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
-  const uint64_t chunk = (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const uint64_t chunk =
+      xcd_local ? (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (uint64_t)blockIdx.x;
   const uint64_t j = chunk * blockDim.x + threadIdx.x;
   if (j >= rows) return;
   const uint64_t pr = pairs[j];
@@ -195,8 +199,9 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
              rows, shift, d_cur, pairs);
   // a multiple of eight workgroups, so that every XCD gets the same number of chunks
+  const int xcd_local = (4ull << shift) <= (2ull << 20);  // a window of ISA entries within half an L2
   BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, pairs,
-             rows, d_isa);
+             rows, d_isa, xcd_local);
   BWT_CHECK_LAUNCH();
   return kOk;
 }

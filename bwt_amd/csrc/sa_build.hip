@@ -146,9 +146,16 @@ __device__ __forceinline__ bool locate_tile_at(uint32_t tile, const Seg *segs,
   return sh->count != 0;
 }
 
+// Scatter workgroups: the hardware deals workgroups to the eight XCDs
+// round-robin, each with its own L2.  Giving XCD x the x-th eighth of the tiles
+// keeps the runs that land next to each other in a bucket (consecutive tiles of
+// one segment) in one L2, where partial lines merge before they are written back.
 __device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *tile_first,
                                             uint32_t nsegs, const Counters *ctr, TileInfo *sh) {
-  return locate_tile_at(blockIdx.x, segs, tile_first, nsegs, ctr, sh);
+  const uint32_t per_xcd = (ctr->total_tiles + 7u) / 8u;
+  const uint32_t seq = blockIdx.x >> 3;
+  const uint32_t tile = seq < per_xcd ? (blockIdx.x & 7u) * per_xcd + seq : 0xFFFFFFFFu;
+  return locate_tile_at(tile, segs, tile_first, nsegs, ctr, sh);
 }
 
 constexpr uint32_t kHistTilesPerGroup = 4;
@@ -1150,7 +1157,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                             scanws, scanws_bytes, s));
     BWT_HIP(hipMemsetAsync(counts, 0, (size_t)nsegs * 256 * 4, s));
     BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
-    const unsigned tile_bound = (unsigned)((uint64_t)n / kPartTile + nsegs + 1);
+    const unsigned tile_bound = (unsigned)(((uint64_t)n / kPartTile + nsegs + 1 + 7) / 8 * 8);  // eighths, see locate_tile
     const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
     const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
     if (src_id == kSrcImplicit) {
