@@ -159,6 +159,65 @@ k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
   }
 }
 
+// Second level for large arrays: the pairs of each first-level bin (a run of
+// 1 << shift1 slots, tiles never straddle two) are dealt into 256 sub-bins by the
+// next eight bits of the position; sub-bin (b, c) owns slots
+// [(b << shift1) + (c << shift2), ...) of the output.
+__global__ void k_isa_cursors2(uint32_t shift1, uint32_t shift2, unsigned long long *__restrict__ cursors) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 65536 of them
+  cursors[i] = ((unsigned long long)(i >> 8) << shift1) + ((unsigned long long)(i & 255u) << shift2);
+}
+
+__global__ void __launch_bounds__(256)
+k_isa_partition2(const uint64_t *__restrict__ in, uint64_t rows, uint32_t shift1, uint32_t shift2,
+                 unsigned long long *__restrict__ cursors /* [256][256] */, uint64_t *__restrict__ out) {
+  __shared__ uint32_t hist[256], lstart[256], fill[256], wsum[4];
+  __shared__ unsigned long long gbase[256];
+  __shared__ uint64_t stage[kIsaTile];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  const uint64_t row0 = (uint64_t)blockIdx.x * kIsaTile;
+  const uint32_t bin1 = (uint32_t)(row0 >> shift1);
+  hist[t] = 0;
+  fill[t] = 0;
+  __syncthreads();
+  uint64_t pr[kIsaTile / 256];
+#pragma unroll
+  for (int i = 0; i < kIsaTile / 256; ++i) {
+    const uint64_t j = row0 + (uint64_t)i * 256 + t;
+    pr[i] = j < rows ? in[j] : 0ull;
+    if (j < rows) atomicAdd(&hist[((uint32_t)pr[i] >> shift2) & 255u], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = hist[t];
+  uint32_t v = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+  lstart[t] = pre + v - c;
+  gbase[t] = c ? atomicAdd(&cursors[bin1 * 256u + t], (unsigned long long)c) : 0ull;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kIsaTile / 256; ++i) {
+    const uint64_t j = row0 + (uint64_t)i * 256 + t;
+    if (j < rows) {
+      const uint32_t b = ((uint32_t)pr[i] >> shift2) & 255u;
+      stage[lstart[b] + atomicAdd(&fill[b], 1u)] = pr[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t placed = lstart[255] + hist[255];
+  for (uint32_t j = t; j < placed; j += 256) {
+    const uint64_t p = stage[j];
+    const uint32_t b = ((uint32_t)p >> shift2) & 255u;
+    out[gbase[b] + (j - lstart[b])] = p;
+  }
+}
+
 // Workgroups go to the eight XCDs round-robin, and each XCD has its own L2:
 // workgroup i takes the chunk of pairs that keeps every XCD inside its own
 // eighth of the pair buffer, so the 4-byte stores into one window meet in one L2
@@ -183,7 +242,8 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
                                 hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1;
   // small arrays sit in L2 whatever the order of the stores
-  const bool force = getenv("BWT_MI355X_ISA_TWO_STEP") != nullptr;  // for tests on small texts
+  const char *env = getenv("BWT_MI355X_ISA_TWO_STEP");  // for tests on small texts: 1 = one level, 2 = two
+  const bool force = env != nullptr, force2 = env && env[0] == '2';
   if (!scratch || (rows <= (1ull << 22) && !force)) {
     BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa);
     return kOk;
@@ -198,11 +258,34 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   BWT_HIP(hipStreamSynchronize(s));  // h_cur leaves the stack
   BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
              rows, shift, d_cur, pairs);
-  // a multiple of eight workgroups, so that every XCD gets the same number of chunks
-  const int xcd_local = (4ull << shift) <= (2ull << 20);  // a window of ISA entries within half an L2
-  BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, pairs,
+  const uint64_t *filled = pairs;
+  uint32_t window_shift = shift;
+  uint64_t *pairs2 = nullptr;
+  unsigned long long *d_cur2 = nullptr;
+  if (((4ull << shift) > (2ull << 20) || force2) && shift >= 12) {
+    // windows beyond an L2: split each bin once more, if there is room for a second pair buffer
+    if (pool_alloc(&pairs2, rows * 8) == hipSuccess && pool_alloc(&d_cur2, 65536 * 8) == hipSuccess) {
+      const uint32_t shift2 = shift - 8;
+      BWT_LAUNCH("isa_cursors2", k_isa_cursors2, dim3(256), dim3(256), 0, s, shift, shift2, d_cur2);
+      BWT_LAUNCH("isa_partition2", k_isa_partition2, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s,
+                 pairs, rows, shift, shift2, d_cur2, pairs2);
+      filled = pairs2;
+      window_shift = shift2;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  const int xcd_local = (4ull << window_shift) <= (2ull << 20);  // a window of ISA entries within half an L2
+  BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, filled,
              rows, d_isa, xcd_local);
-  BWT_CHECK_LAUNCH();
+  hipError_t e = hipGetLastError();
+  if (pairs2 || d_cur2) {
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // before the buffers go back to the pool
+    else (void)hipDeviceSynchronize();
+    pool_free(pairs2);
+    pool_free(d_cur2);
+  }
+  if (e != hipSuccess) return set_error(kErrHip, "inverse suffix array: %s", hipGetErrorString(e));
   return kOk;
 }
 

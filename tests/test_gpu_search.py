@@ -269,13 +269,14 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     assert loads["kmer_entries_8B"] == (3000 if k >= 2 else 0)
 
 
+@pytest.mark.parametrize("levels", ["1", "2"])
 @pytest.mark.parametrize("n", [5000, 100003, 3000000])
-def test_two_step_inverse_suffix_array(oracle, gpu, n, monkeypatch):
+def test_two_step_inverse_suffix_array(oracle, gpu, n, levels, monkeypatch):
     """Large texts build the inverse suffix array by partition + fill; forced
     here on small ones.  Every search that ends in the text comparison reads it."""
     text = oracle.gen_genome(n, 555 + n)
     fo = oracle.make_fmi(text, n)
-    monkeypatch.setenv("BWT_MI355X_ISA_TWO_STEP", "1")
+    monkeypatch.setenv("BWT_MI355X_ISA_TWO_STEP", levels)
     ix = gpu.build_index(text, n)
     monkeypatch.delenv("BWT_MI355X_ISA_TWO_STEP")
     R, m = 20000, 60

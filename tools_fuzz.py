@@ -78,7 +78,7 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
             else:
                 os.environ.pop("BWT_MI355X_KMER", None)
             if rng.integers(0, 3) == 0:
-                os.environ["BWT_MI355X_ISA_TWO_STEP"] = "1"
+                os.environ["BWT_MI355X_ISA_TWO_STEP"] = "12"[int(rng.integers(0, 2))]
             else:
                 os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
             t = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
