@@ -92,12 +92,48 @@ __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, i
 // COUNT adds up what the batch loaded (see bwtgpu_search_profile): counters[0]
 // 16-byte rank blocks, [1] 8-byte text windows, [2] 4-byte SA/ISA entries,
 // [3] 4-byte pattern words, [4] 8-byte k-mer table entries.
-template <bool VERIFY, bool COUNT>
+//
+// FUSED: the reads are packed inside the kernel instead of by k_pack_reads: a
+// workgroup stages the bytes of its 256 reads in LDS, packs them into LDS
+// words and searches from there, so the packed form never goes to HBM.  Used
+// when bytes and words of 256 reads fit kFusedLdsBytes.
+template <bool VERIFY, bool COUNT, bool FUSED>
 __global__ void __launch_bounds__(256)
-k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R, uint32_t m,
-         uint32_t *__restrict__ d_sp, uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
+k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
+         uint64_t stride, uint64_t R, uint32_t m, uint32_t *__restrict__ d_sp,
+         uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
          unsigned long long *__restrict__ counters) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint32_t t = threadIdx.x;
+  const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
+  const uint64_t r = r0 + t;
+  const uint32_t *lw = nullptr;  // FUSED: word w of this lane's read at lw[w * 256]
+  if (FUSED) {
+    const uint32_t words = (m + 15) / 16;
+    uint32_t *wbase = reinterpret_cast<uint32_t *>(lds);  // [words][256], then the staged bytes
+    uint8_t *bytes = lds + (size_t)words * 256 * 4;
+    const uint8_t *src = pats + r0 * stride;
+    const uint64_t last = R - 1 < r0 + 255 ? R - 1 : r0 + 255;
+    const uint32_t span = (uint32_t)((last - r0) * stride + m);
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
+    const uint8_t *asrc = src - mis;  // see k_pack_reads
+    const uint32_t total = mis + span, vecs = total / 16;
+    for (uint32_t i = t; i < vecs; i += 256)
+      reinterpret_cast<uint4 *>(bytes)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
+    for (uint32_t i = vecs * 16 + t; i < total; i += 256) bytes[i] = asrc[i];
+    __syncthreads();
+    if (r < R) {
+      const uint8_t *mine = bytes + mis + (uint32_t)(t * stride);
+      for (uint32_t w = 0; w < words; ++w) {
+        uint32_t acc = 0;
+        const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
+        for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
+        wbase[w * 256 + t] = acc;
+      }
+    }
+    lw = wbase + t;  // only this lane reads its own words: no barrier needed
+  }
+  auto word_at = [&](uint32_t w) -> uint32_t { return FUSED ? lw[w * 256] : packed[(uint64_t)w * R + r]; };
   uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1, n_kmr = 0;
   if (r < R) {
   int i = -2;
@@ -106,8 +142,8 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   if (K && m >= K) {
     // the last K bases as a base-4 number, first base most significant
     const uint32_t a = m - K, wa = a >> 4;
-    const uint32_t w0 = packed[(uint64_t)wa * R + r];
-    const uint32_t w1 = wa < ((m - 1) >> 4) ? packed[(uint64_t)(wa + 1) * R + r] : 0u;
+    const uint32_t w0 = word_at((uint32_t)(wa));
+    const uint32_t w1 = wa < ((m - 1) >> 4) ? word_at((uint32_t)(wa + 1)) : 0u;
     if (COUNT) n_pat += wa < ((m - 1) >> 4);
     uint32_t x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (a & 15u)));  // base a in the low bits
     x = __brev(x);
@@ -123,7 +159,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   }
   if (i == -2) {  // no table, a short read, or a string the text does not hold: step by step
     i = (int)m - 1;
-    word = packed[(uint64_t)(i >> 4) * R + r];
+    word = word_at((uint32_t)(i >> 4));
     c = (word >> (2 * (i & 15))) & 3u;
     sp = c == 0 ? C.c[0] : c == 1 ? C.c[1] : c == 2 ? C.c[2] : C.c[3];
     ep = c == 0 ? C.c[1] : c == 1 ? C.c[2] : c == 2 ? C.c[3] : C.c[4];
@@ -133,7 +169,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
   const uint4 *sym = reinterpret_cast<const uint4 *>(v.sym);
   for (; i >= 0; --i) {
     if ((i & 15) == 15) {
-      word = packed[(uint64_t)(i >> 4) * R + r];
+      word = word_at((uint32_t)(i >> 4));
       if (COUNT) ++n_pat;
     }
     if (ep <= sp) {  // seqindex.c:299-301
@@ -165,7 +201,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
       const uint32_t lo = jmin > 16u * w ? jmin - 16u * w : 0u;
       if (lo >= 16) break;
       const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
-      const uint32_t rw = packed[(uint64_t)w * R + r];
+      const uint32_t rw = word_at((uint32_t)(w));
       const uint32_t tw = text16(v.text2, (int64_t)pos - rem + 16 * w);
       if (COUNT) {
         ++n_txt;
@@ -184,7 +220,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, uint64_t R,
     } else {
       const uint32_t k = rem - 1 - (uint32_t)jbad;  // bases that did match
       const uint32_t row = k ? v.isa[pos - k] : sp;
-      c = (packed[(uint64_t)(jbad >> 4) * R + r] >> (2 * (jbad & 15))) & 3u;
+      c = (word_at((uint32_t)(jbad >> 4)) >> (2 * (jbad & 15))) & 3u;
       const uint32_t js = row - (row > v.endloc), je = row + 1 - (row + 1 > v.endloc);
       uint32_t rs, re;
       const uint32_t bs = div96(js, rs), be = div96(je, re);
@@ -335,6 +371,8 @@ size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m) {
   return align_up((size_t)((m + 15) / 16) * R * sizeof(uint32_t), 256) + 256;
 }
 
+constexpr uint32_t kFusedLdsBytes = 24 * 1024;
+
 static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                        uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                        size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
@@ -350,27 +388,39 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   const uint64_t groups = div_up(R, kPackThreads);
   if (groups > 0x7FFFFFFFull) return set_error(kErrArg, "too many reads for one launch");
   const uint64_t span = (uint64_t)(kPackThreads - 1) * stride + m + 16;
-  const int use_lds = span <= kPackLdsBytes;
-  BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),
-             use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
-  BWT_CHECK_LAUNCH();
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   const dim3 grid((unsigned)div_up(R, 256)), block(256);
   const IndexView v = view_of(ix);
+  // bytes and packed words of a workgroup's 256 reads in LDS: pack inside the search kernel
+  const uint64_t fused_lds = align_up(span, 16) + (uint64_t)((m + 15) / 16) * 256 * 4;
+  if (!d_counters && fused_lds <= kFusedLdsBytes) {
+    if (ix->d_sa)
+      BWT_LAUNCH("fm_search", (k_search<true, false, true>), grid, block, (size_t)fused_lds, s, v, C, packed,
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+    else
+      BWT_LAUNCH("fm_search", (k_search<false, false, true>), grid, block, (size_t)fused_lds, s, v, C, packed,
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+    BWT_CHECK_LAUNCH();
+    return kOk;
+  }
+  const int use_lds = span <= kPackLdsBytes;
+  BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),
+             use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
+  BWT_CHECK_LAUNCH();
   if (d_counters) {
     if (ix->d_sa)
-      BWT_LAUNCH("fm_search_counting", (k_search<true, true>), grid, block, 0, s, v, C, packed, R, m, d_sp,
-                 d_ep, d_locrow, d_counters);
+      BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters);
     else
-      BWT_LAUNCH("fm_search_counting", (k_search<false, true>), grid, block, 0, s, v, C, packed, R, m, d_sp,
-                 d_ep, d_locrow, d_counters);
+      BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters);
   } else if (ix->d_sa) {
-    BWT_LAUNCH("fm_search", (k_search<true, false>), grid, block, 0, s, v, C, packed, R, m, d_sp, d_ep,
-               d_locrow, d_counters);
+    BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
+               d_sp, d_ep, d_locrow, d_counters);
   } else {
-    BWT_LAUNCH("fm_search", (k_search<false, false>), grid, block, 0, s, v, C, packed, R, m, d_sp, d_ep,
-               d_locrow, d_counters);
+    BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R,
+               m, d_sp, d_ep, d_locrow, d_counters);
   }
   BWT_CHECK_LAUNCH();
   return kOk;
