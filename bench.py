@@ -277,7 +277,10 @@ def main():
     G.timing_enable(False)
     loads, sp_c, ep_c = ix.search_loads(d_reads, m, R)
     counted_ok = bool(torch.equal(sp_c, sp) and torch.equal(ep_c, ep))
-    bpr = loads["bytes"] / R + 12.0  # + sp, ep, locate row written
+    # + sp, ep, locate row written; when the kernel packs the reads itself (no pack_reads
+    # launch) it reads their m bytes once instead of the packed words
+    fused = "pack_reads" not in search_kernels
+    bpr = (loads["bytes"] - (4 * loads["pattern_words_4B"] if fused else 0)) / R + (m if fused else 0) + 12.0
     achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
     index_bytes = ix.device_bytes
 
@@ -335,7 +338,9 @@ def main():
             "counting_pass_matches": counted_ok,
             "kernel_ms": k_ms,
             "what": "bytes the kernel loads and stores, counted per batch by its counting build "
-                    "(16 B rank blocks, 8 B text windows, 4 B SA/ISA entries, packed pattern words, 12 B out)",
+                    "(16 B rank blocks, 8 B text windows, 4 B SA/ISA entries, 8 B table entry, the read itself, "
+                    "12 B out)",
+            "reads_packed_in_kernel": fused,
         },
         "rank_only": {
             "what": "same batch after dropping SA/ISA/text from the index: every step is two rank queries",

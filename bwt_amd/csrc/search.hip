@@ -371,7 +371,7 @@ size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m) {
   return align_up((size_t)((m + 15) / 16) * R * sizeof(uint32_t), 256) + 256;
 }
 
-constexpr uint32_t kFusedLdsBytes = 24 * 1024;
+constexpr uint32_t kFusedLdsBytes = 40 * 1024;
 
 static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                        uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
