@@ -739,7 +739,9 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   }
   // equal keys are rare (none in most leaves of a random text): only then are
   // runs settled by deeper comparison, in LDS, and the window read again
-  if (__syncthreads_or(any_equal)) {
+  const bool ties = __syncthreads_or(any_equal);  // also: every thread has read its window
+  uint64_t outv[16];
+  if (ties) {
     // short runs of equal keys: the thread that owns the first row of a run
     // orders the whole run by comparing the suffixes beyond the key
     for (uint32_t k = 0; k < per; ++k) {
@@ -769,75 +771,86 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     }
     __syncthreads();
     load_window();
-  }
-  uint32_t hv[16];
-  uint32_t local_max = 0, tied_rows = 0;
-#pragma unroll
-  for (uint32_t k = 0; k < 16; ++k) {
-    hv[k] = 0;
-    const uint32_t j = j0 + k;
-    if (k < per && j < size) {
-      bool tie = false, tie_next = false;
-      const uint64_t cur = w[k + 1];
-      if (j > 0) {
-        const uint64_t prv = w[k];
-        const uint32_t pid = word_id(prv);
-        // the previous suffix is final here if its key window ran past the
-        // end of the text: a shorter suffix precedes every longer one it ties
-        tie = word_key(prv) == word_key(cur) &&
-              (uint64_t)pid + depth + keybases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
+    uint32_t hv[16];
+    uint32_t local_max = 0, tied_rows = 0;
+  #pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+      hv[k] = 0;
+      const uint32_t j = j0 + k;
+      if (k < per && j < size) {
+        bool tie = false, tie_next = false;
+        const uint64_t cur = w[k + 1];
+        if (j > 0) {
+          const uint64_t prv = w[k];
+          const uint32_t pid = word_id(prv);
+          // the previous suffix is final here if its key window ran past the
+          // end of the text: a shorter suffix precedes every longer one it ties
+          tie = word_key(prv) == word_key(cur) &&
+                (uint64_t)pid + depth + keybases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
+        }
+        if (j + 1 < size) {
+          const uint64_t nxt = w[k + 2];
+          const uint32_t cid = word_id(cur);
+          tie_next = word_key(nxt) == word_key(cur) &&
+                     (uint64_t)cid + depth + keybases < n &&
+                     !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
+        }
+        hv[k] = tie ? 0u : 1u + start + j;
+        tied_rows += (tie || tie_next) ? 1u : 0u;
+        local_max = hv[k] > local_max ? hv[k] : local_max;
       }
-      if (j + 1 < size) {
-        const uint64_t nxt = w[k + 2];
-        const uint32_t cid = word_id(cur);
-        tie_next = word_key(nxt) == word_key(cur) &&
-                   (uint64_t)cid + depth + keybases < n &&
-                   !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
+    }
+    // inclusive max-scan of local_max over threads
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    uint32_t v = local_max;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v = u > v ? u : v;
+    }
+    uint32_t tr = tied_rows;
+    for (int off = 32; off; off >>= 1) tr += __shfl_down(tr, off, 64);
+    if (lane == 63) wmax[wave] = v;
+    if (lane == 0) wred[wave] = tr;
+    __syncthreads();
+    uint32_t before = 0;  // max over all earlier threads
+    for (uint32_t q = 0; q < wave; ++q) before = wmax[q] > before ? wmax[q] : before;
+    const uint32_t up = __shfl_up(v, 1, 64);
+    if (lane) before = up > before ? up : before;
+    if (t == 0) {
+      const uint32_t total = wred[0] + wred[1] + wred[2] + wred[3];
+      if (total) {
+        atomicAdd(&ctr->unresolved, total);
+        atomicMin(&ctr->min_depth, depth + keybases);
       }
-      hv[k] = tie ? 0u : 1u + start + j;
-      tied_rows += (tie || tie_next) ? 1u : 0u;
-      local_max = hv[k] > local_max ? hv[k] : local_max;
     }
-  }
-  // inclusive max-scan of local_max over threads
-  const uint32_t lane = t & 63u, wave = t >> 6;
-  uint32_t v = local_max;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t u = __shfl_up(v, off, 64);
-    if (lane >= off) v = u > v ? u : v;
-  }
-  uint32_t tr = tied_rows;
-  for (int off = 32; off; off >>= 1) tr += __shfl_down(tr, off, 64);
-  if (lane == 63) wmax[wave] = v;
-  if (lane == 0) wred[wave] = tr;
-  __syncthreads();
-  uint32_t before = 0;  // max over all earlier threads
-  for (uint32_t q = 0; q < wave; ++q) before = wmax[q] > before ? wmax[q] : before;
-  const uint32_t up = __shfl_up(v, 1, 64);
-  if (lane) before = up > before ? up : before;
-  if (t == 0) {
-    const uint32_t total = wred[0] + wred[1] + wred[2] + wred[3];
-    if (total) {
-      atomicAdd(&ctr->unresolved, total);
-      atomicMin(&ctr->min_depth, depth + keybases);
+    // every thread has read its neighbours' keys; now reuse the LDS slots
+    uint32_t run = before;
+  #pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint32_t j = j0 + k;
+      if (k < per && j < size) {
+        const uint64_t cur = w[k + 1];
+        const uint32_t id = word_id(cur);
+        run = hv[k] > run ? hv[k] : run;
+        // head row relative to the leaf (12 bits), BWT symbol, id: one word per row
+        outv[k] = ((uint64_t)(cur & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
+        if (id == 0) ctr->endloc = 1 + start + j;
+      }
     }
-  }
-  // every thread has read its neighbours' keys; now reuse the LDS slots
-  uint32_t run = before;
-  uint64_t outv[16];
+    __syncthreads();  // neighbours' keys have been read; the LDS slots are reused below
+  } else {
+    // no two neighbouring keys are equal: every row is its own group
 #pragma unroll
-  for (uint32_t k = 0; k < 16; ++k) {
-    const uint32_t j = j0 + k;
-    if (k < per && j < size) {
-      const uint64_t cur = w[k + 1];
-      const uint32_t id = word_id(cur);
-      run = hv[k] > run ? hv[k] : run;
-      // head row relative to the leaf (12 bits), BWT symbol, id: one word per row
-      outv[k] = ((uint64_t)(cur & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
-      if (id == 0) ctr->endloc = 1 + start + j;
+    for (uint32_t k = 0; k < 16; ++k) {
+      const uint32_t j = j0 + k;
+      if (k < per && j < size) {
+        const uint64_t cur = w[k + 1];
+        const uint32_t id = word_id(cur);
+        outv[k] = ((uint64_t)(cur & 3u) << 44) | ((uint64_t)j << 32) | id;
+        if (id == 0) ctr->endloc = 1 + start + j;
+      }
     }
   }
-  __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < 16; ++k) {
     const uint32_t j = j0 + k;
