@@ -163,6 +163,10 @@ k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
 // 1 << shift1 slots, tiles never straddle two) are dealt into 256 sub-bins by the
 // next eight bits of the position; sub-bin (b, c) owns slots
 // [(b << shift1) + (c << shift2), ...) of the output.
+__global__ void k_isa_cursors1(uint32_t shift, unsigned long long *__restrict__ cursors) {
+  cursors[threadIdx.x] = (unsigned long long)threadIdx.x << shift;  // bin b starts at slot b << shift
+}
+
 __global__ void k_isa_cursors2(uint32_t shift1, uint32_t shift2, unsigned long long *__restrict__ cursors) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 65536 of them
   cursors[i] = ((unsigned long long)(i >> 8) << shift1) + ((unsigned long long)(i & 255u) << shift2);
@@ -250,12 +254,9 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   }
   uint32_t shift = 0;
   while (((uint64_t)n >> shift) > 255) ++shift;
-  unsigned long long h_cur[256];
-  for (uint32_t b = 0; b < 256; ++b) h_cur[b] = (unsigned long long)b << shift;
   unsigned long long *d_cur = reinterpret_cast<unsigned long long *>(scratch);
   uint64_t *pairs = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(scratch) + 2048);
-  BWT_HIP(hipMemcpyAsync(d_cur, h_cur, sizeof h_cur, hipMemcpyHostToDevice, s));
-  BWT_HIP(hipStreamSynchronize(s));  // h_cur leaves the stack
+  BWT_LAUNCH("isa_cursors", k_isa_cursors1, dim3(1), dim3(256), 0, s, shift, d_cur);
   BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
              rows, shift, d_cur, pairs);
   const uint64_t *filled = pairs;
