@@ -96,7 +96,8 @@ __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, i
 // FUSED: the reads are packed inside the kernel instead of by k_pack_reads: a
 // workgroup stages the bytes of its 256 reads in LDS, packs them into LDS
 // words and searches from there, so the packed form never goes to HBM.  Used
-// when bytes and words of 256 reads fit kFusedLdsBytes.
+// when bytes and words of a workgroup's reads (256, 128 or 64 of them) fit
+// kFusedLdsBytes.
 template <bool VERIFY, bool COUNT, bool FUSED>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
@@ -107,20 +108,21 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   const uint32_t t = threadIdx.x;
   const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
   const uint64_t r = r0 + t;
-  const uint32_t *lw = nullptr;  // FUSED: word w of this lane's read at lw[w * 256]
+  const uint32_t *lw = nullptr;  // FUSED: word w of this lane's read at lw[w * blockDim.x]
+  const uint32_t nt = blockDim.x;  // reads per workgroup: 256, fewer for long reads in the fused form
   if (FUSED) {
     const uint32_t words = (m + 15) / 16;
-    uint32_t *wbase = reinterpret_cast<uint32_t *>(lds);  // [words][256], then the staged bytes
-    uint8_t *bytes = lds + (size_t)words * 256 * 4;
+    uint32_t *wbase = reinterpret_cast<uint32_t *>(lds);  // [words][nt], then the staged bytes
+    uint8_t *bytes = lds + (size_t)words * nt * 4;
     const uint8_t *src = pats + r0 * stride;
-    const uint64_t last = R - 1 < r0 + 255 ? R - 1 : r0 + 255;
+    const uint64_t last = R - 1 < r0 + nt - 1 ? R - 1 : r0 + nt - 1;
     const uint32_t span = (uint32_t)((last - r0) * stride + m);
     const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
     const uint8_t *asrc = src - mis;  // see k_pack_reads
     const uint32_t total = mis + span, vecs = total / 16;
-    for (uint32_t i = t; i < vecs; i += 256)
+    for (uint32_t i = t; i < vecs; i += nt)
       reinterpret_cast<uint4 *>(bytes)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
-    for (uint32_t i = vecs * 16 + t; i < total; i += 256) bytes[i] = asrc[i];
+    for (uint32_t i = vecs * 16 + t; i < total; i += nt) bytes[i] = asrc[i];
     __syncthreads();
     if (r < R) {
       const uint8_t *mine = bytes + mis + (uint32_t)(t * stride);
@@ -128,12 +130,12 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
         uint32_t acc = 0;
         const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
         for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
-        wbase[w * 256 + t] = acc;
+        wbase[w * nt + t] = acc;
       }
     }
     lw = wbase + t;  // only this lane reads its own words: no barrier needed
   }
-  auto word_at = [&](uint32_t w) -> uint32_t { return FUSED ? lw[w * 256] : packed[(uint64_t)w * R + r]; };
+  auto word_at = [&](uint32_t w) -> uint32_t { return FUSED ? lw[w * nt] : packed[(uint64_t)w * R + r]; };
   uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1, n_kmr = 0;
   if (r < R) {
   int i = -2;
@@ -392,17 +394,25 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   const dim3 grid((unsigned)div_up(R, 256)), block(256);
   const IndexView v = view_of(ix);
-  // bytes and packed words of a workgroup's 256 reads in LDS: pack inside the search kernel
-  const uint64_t fused_lds = align_up(span, 16) + (uint64_t)((m + 15) / 16) * 256 * 4;
-  if (!d_counters && fused_lds <= kFusedLdsBytes) {
-    if (ix->d_sa)
-      BWT_LAUNCH("fm_search", (k_search<true, false, true>), grid, block, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
-    else
-      BWT_LAUNCH("fm_search", (k_search<false, false, true>), grid, block, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
-    BWT_CHECK_LAUNCH();
-    return kOk;
+  // bytes and packed words of a workgroup's reads in LDS: pack inside the search kernel.
+  // Long reads get smaller workgroups so that they still fit.
+  if (!d_counters) {
+    for (uint32_t nt = 256; nt >= 64; nt /= 2) {
+      const uint64_t bytes = align_up((uint64_t)(nt - 1) * stride + m + 16, 16);
+      const uint64_t fused_lds = bytes + (uint64_t)((m + 15) / 16) * nt * 4;
+      if (fused_lds > kFusedLdsBytes) continue;
+      const uint64_t wgs = div_up(R, nt);
+      if (wgs > 0x7FFFFFFFull) break;
+      const dim3 fgrid((unsigned)wgs), fblock(nt);
+      if (ix->d_sa)
+        BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
+                   d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+      else
+        BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
+                   d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+      BWT_CHECK_LAUNCH();
+      return kOk;
+    }
   }
   const int use_lds = span <= kPackLdsBytes;
   BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),

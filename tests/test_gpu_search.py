@@ -31,7 +31,8 @@ def test_rank_blocks_match_seq_index(oracle, gpu, n):
 
 
 @pytest.mark.parametrize("n,R,m", [(777, 500, 12), (100003, 5000, 20), (1000000, 10000, 20),
-                                   (1000000, 20000, 50), (1000000, 3000, 100), (1000000, 1000, 17)])
+                                   (1000000, 20000, 50), (1000000, 3000, 100), (1000000, 1000, 17),
+                                   (1000000, 3000, 150), (1000000, 2001, 251), (1000000, 700, 600)])
 def test_search_matches_loc_search(oracle, gpu, n, R, m):
     text, fo, ix = _index_pair(oracle, gpu, n)
     reads, offs = oracle.gen_reads(text, n, R, m, synth.READS_SEED)
