@@ -51,10 +51,14 @@ __device__ __forceinline__ uint32_t text_base2(const IndexView &v, uint32_t p) {
 // the text in front of that row's suffix -- an N there always agrees, being
 // read as the one base that precedes the row -- and the last non-empty
 // interval is the row of the suffix that many bases earlier.
-__device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int len,
-                                       uint32_t *sp_out, uint32_t *ep_out) {
+//
+// Symbol i of the pattern is pat[i * step]: step = -1 reads a buffer backwards
+// (the reversed read of search_reads without a second copy).  pat may point
+// into LDS.
+__device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int step,
+                                       int len, uint32_t *sp_out, uint32_t *ep_out) {
   int skips = 0;
-  while (len > 0 && pat[len - 1] == 5) {
+  while (len > 0 && pat[(len - 1) * step] == 5) {
     --len;
     ++skips;
   }
@@ -63,7 +67,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     *ep_out = 0;
     return skips;
   }
-  uint32_t c = pat[len - 1] & 3u;
+  uint32_t c = pat[(len - 1) * step] & 3u;
   uint32_t start = c_of(C, c), end = c_of(C, c + 1);
   int i = len - 2;
   const int K = (int)v.kmer_k;
@@ -71,7 +75,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     uint32_t x = 0;
     bool plain = true;
     for (int k = 0; k < K; ++k) {
-      const uint32_t raw = pat[len - K + k];
+      const uint32_t raw = pat[(len - K + k) * step];
       plain = plain && raw != 5;
       x = (x << 2) | (raw & 3u);
     }
@@ -93,7 +97,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
       const uint32_t pos = v.sa[start];
       uint32_t k = 0;  // bases that agree with the text in front of pos
       while ((int)k <= i && k < pos) {
-        const uint32_t raw = pat[i - (int)k];
+        const uint32_t raw = pat[(i - (int)k) * step];
         if (raw != 5 && (raw & 3u) != text_base2(v, pos - 1 - k)) break;
         ++k;
       }
@@ -102,7 +106,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
       *ep_out = row + 1;
       return len - 1 - i + (int)k + skips;
     }
-    const uint32_t raw = pat[i];
+    const uint32_t raw = pat[i * step];
     if (raw == 5) {
       uint32_t a[4], b[4];
       occ_all(v, start, a);
@@ -146,14 +150,40 @@ __device__ __forceinline__ uint32_t unc_sa_dev(const IndexView &v, uint32_t idx)
   return (uint32_t)x;
 }
 
+// Bytes [lo, hi) of a global buffer into LDS with 16-byte loads where the
+// alignment allows; returns where byte lo landed.  All threads of the
+// workgroup call it; ends with a barrier.
+__device__ __forceinline__ const uint8_t *stage_bytes(const uint8_t *__restrict__ g, uint64_t lo, uint64_t hi,
+                                                      uint8_t *lds) {
+  const uint8_t *src = g + lo;
+  const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
+  const uint8_t *asrc = src - mis;  // same 16-byte granule as src: inside the allocation
+  const uint32_t total = mis + (uint32_t)(hi - lo), vecs = total / 16;
+  for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x)
+    reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
+  for (uint32_t i = vecs * 16 + threadIdx.x; i < total; i += blockDim.x) lds[i] = asrc[i];
+  __syncthreads();
+  return lds + mis;
+}
+
+// lds_bytes != 0: the workgroup's patterns are staged in LDS first (coalesced
+// loads instead of one byte per lane and step).
 __global__ void __launch_bounds__(256)
 k_mms_batch(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride,
             uint64_t R, int32_t *__restrict__ matched, uint32_t *__restrict__ d_sp,
-            uint32_t *__restrict__ d_ep) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+            uint32_t *__restrict__ d_ep, uint32_t lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
+  const uint64_t r = r0 + threadIdx.x;
+  const uint8_t *mine = pats + r * stride;
+  if (lds_bytes) {
+    const uint64_t last = R - 1 < r0 + blockDim.x - 1 ? R - 1 : r0 + blockDim.x - 1;
+    const uint8_t *base = stage_bytes(pats, r0 * stride, last * stride + m, lds);
+    mine = base + (uint32_t)(threadIdx.x * stride);
+  }
   if (r >= R) return;
   uint32_t sp, ep;
-  matched[r] = mms_dev(v, C, pats + r * stride, (int)m, &sp, &ep);
+  matched[r] = mms_dev(v, C, mine, 1, (int)m, &sp, &ep);
   d_sp[r] = sp;
   d_ep[r] = ep;
 }
@@ -167,18 +197,33 @@ k_mms_batch(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, u
 __global__ void __launch_bounds__(256)
 k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
                const uint8_t *__restrict__ reversed, const uint64_t *__restrict__ offsets,
-               uint64_t R, int anchor, uint32_t *__restrict__ out) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+               uint64_t R, int anchor, uint32_t *__restrict__ out, uint32_t lds_bytes) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
+  const uint64_t r = r0 + threadIdx.x;
+  const uint64_t rl = r < R ? r : R - 1;  // lanes past the end stage nothing of their own
+  const uint64_t o = offsets[rl];
+  const int full = (int)(offsets[rl + 1] - o);
+  const uint8_t *fwd = reads + o, *bwd = reversed + o;
+  int bstep = 1;
+  if (lds_bytes) {
+    // the workgroup's reads lie back to back: one staged copy serves both
+    // directions, the reversed read being the same bytes from the other end
+    const uint64_t lo = offsets[r0], hi = offsets[R < r0 + blockDim.x ? R : r0 + blockDim.x];
+    const uint8_t *base = stage_bytes(reads, lo, hi, lds);
+    fwd = base + (uint32_t)(o - lo);
+    bwd = fwd + (full - 1);
+    bstep = -1;
+  }
   if (r >= R) return;
-  const uint64_t o = offsets[r];
-  const int full = (int)(offsets[r + 1] - o);
   uint32_t res[4] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (int dir = 0; dir < 2; ++dir) {
-    const uint8_t *p = (dir ? reversed : reads) + o;
+    const uint8_t *p = dir ? bwd : fwd;
+    const int step = dir ? bstep : 1;
     int len = full;
     while (len > anchor) {  // search_reads.c:115
       uint32_t sp, ep;
-      const int got = mms_dev(v, C, p, len, &sp, &ep);
+      const int got = mms_dev(v, C, p, step, len, &sp, &ep);
       if (got >= anchor) {  // :119-127
         res[dir]++;
         len -= got;
@@ -189,6 +234,18 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
     }
   }
   reinterpret_cast<uint4 *>(out)[r] = make_uint4(res[0], res[1], res[2], res[3]);
+}
+
+constexpr uint32_t kMmsLdsBytes = 40 * 1024;
+
+// largest number of bytes the reads of one workgroup (nt consecutive reads) span
+__global__ void k_max_group_span(const uint64_t *__restrict__ offsets, uint64_t R, uint32_t nt,
+                                 unsigned long long *__restrict__ out) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r0 = g * nt;
+  if (r0 >= R) return;
+  const uint64_t r1 = r0 + nt < R ? r0 + nt : R;
+  atomicMax(out, (unsigned long long)(offsets[r1] - offsets[r0]));
 }
 
 }  // namespace bwtgpu
@@ -204,8 +261,18 @@ int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64
   if (R == 0) return kOk;
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
-  BWT_LAUNCH("fm_mms", k_mms_batch, dim3((unsigned)div_up(R, 256)), dim3(256), 0, (hipStream_t)stream,
-             view_of(ix), C, d_pats, m, stride, R, d_matched, d_sp, d_ep);
+  // patterns of a workgroup through LDS when they fit (smaller workgroups for long patterns)
+  uint32_t nt = 256, lds_bytes = 0;
+  for (; nt >= 64; nt /= 2) {
+    const uint64_t need = align_up((uint64_t)(nt - 1) * stride + m + 16, 16);
+    if (need <= kMmsLdsBytes) {
+      lds_bytes = (uint32_t)need;
+      break;
+    }
+  }
+  if (!lds_bytes) nt = 256;
+  BWT_LAUNCH("fm_mms", k_mms_batch, dim3((unsigned)div_up(R, nt)), dim3(nt), lds_bytes, (hipStream_t)stream,
+             view_of(ix), C, d_pats, m, stride, R, d_matched, d_sp, d_ep, lds_bytes);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
@@ -218,8 +285,24 @@ int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads, const ui
   if (R == 0) return kOk;
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
-  BWT_LAUNCH("fm_search_reads", k_search_reads, dim3((unsigned)div_up(R, 256)), dim3(256), 0,
-             (hipStream_t)stream, view_of(ix), C, d_reads, d_reversed, d_offsets, R, anchor, d_out);
+  hipStream_t s = (hipStream_t)stream;
+  // reads of a workgroup through LDS when the longest group fits: needs one number from the device
+  unsigned long long *d_span = nullptr, h_span = 0;
+  BWT_HIP(pool_alloc(&d_span, 256));
+  hipError_t e = hipMemsetAsync(d_span, 0, 8, s);
+  if (e == hipSuccess) {
+    const uint64_t groups = div_up(R, 256);
+    BWT_LAUNCH("fm_search_reads_span", k_max_group_span, dim3((unsigned)div_up(groups, 256)), dim3(256), 0, s,
+               d_offsets, R, 256u, d_span);
+    e = hipMemcpyAsync(&h_span, d_span, 8, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  pool_free(d_span);
+  if (e != hipSuccess) return set_error(kErrHip, "search_reads: %s", hipGetErrorString(e));
+  const uint64_t need = align_up(h_span + 32, 16);
+  const uint32_t lds_bytes = need <= kMmsLdsBytes ? (uint32_t)need : 0u;
+  BWT_LAUNCH("fm_search_reads", k_search_reads, dim3((unsigned)div_up(R, 256)), dim3(256), lds_bytes, s,
+             view_of(ix), C, d_reads, d_reversed, d_offsets, R, anchor, d_out, lds_bytes);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
