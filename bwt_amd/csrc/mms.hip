@@ -55,8 +55,13 @@ __device__ __forceinline__ uint32_t text_base2(const IndexView &v, uint32_t p) {
 // Symbol i of the pattern is pat[i * step]: step = -1 reads a buffer backwards
 // (the reversed read of search_reads without a second copy).  pat may point
 // into LDS.
+//
+// at_least: the caller only asks whether the result reaches this length (the
+// anchor test of search_reads); when the table shows that the last k bases do
+// not occur and k <= at_least, the answer is "no" without a single rank query
+// and 0 is returned.  0 asks for the exact value.
 __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int step,
-                                       int len, uint32_t *sp_out, uint32_t *ep_out) {
+                                       int len, uint32_t *sp_out, uint32_t *ep_out, int at_least) {
   int skips = 0;
   while (len > 0 && pat[(len - 1) * step] == 5) {
     --len;
@@ -85,6 +90,11 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
         start = e.x;
         end = e.y;
         i = len - K - 1;
+      } else if (K <= at_least && skips == 0) {
+        // fewer than K bases match and none was skipped: below the caller's bar
+        *sp_out = 0;
+        *ep_out = 0;
+        return 0;
       }
     }
   }
@@ -183,7 +193,7 @@ k_mms_batch(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, u
   }
   if (r >= R) return;
   uint32_t sp, ep;
-  matched[r] = mms_dev(v, C, mine, 1, (int)m, &sp, &ep);
+  matched[r] = mms_dev(v, C, mine, 1, (int)m, &sp, &ep, 0);
   d_sp[r] = sp;
   d_ep[r] = ep;
 }
@@ -223,7 +233,7 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
     int len = full;
     while (len > anchor) {  // search_reads.c:115
       uint32_t sp, ep;
-      const int got = mms_dev(v, C, p, step, len, &sp, &ep);
+      const int got = mms_dev(v, C, p, step, len, &sp, &ep, anchor);
       if (got >= anchor) {  // :119-127
         res[dir]++;
         len -= got;
