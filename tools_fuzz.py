@@ -124,6 +124,32 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 want = [orc.mms(fo, readsn[r]) for r in range(200)]
                 for name, ix in (("full", full), ("lean", lean)):
                     assert mms_gpu(ix, readsn) == want, f"mms {name} m={m}"
+            # search_reads anchor loop on reads of mixed lengths, with substitutions and N
+            enc = []
+            for _ in range(60):
+                L = int(rng.integers(1, 160))
+                if n >= L and rng.integers(0, 6):
+                    j = int(rng.integers(0, n - L + 1)); e = bases[j:j + L].copy()
+                    for _ in range(int(rng.integers(0, 3))):
+                        q = int(rng.integers(0, L)); e[q] = (e[q] + 1) & 3
+                else:
+                    e = rng.integers(0, 4, L).astype(np.uint8)
+                if L >= 2 and rng.integers(0, 5) == 0:
+                    e[rng.integers(0, L)] = 5
+                if e[-1] == 5 and (e == 5).all():
+                    e[0] = 0
+                enc.append(e.astype(np.uint8))
+            anchor = int(rng.integers(1, 30))
+            want = np.array([orc.search_reads_one(fo, e, anchor) for e in enc], np.uint32)
+            offs = np.zeros(len(enc) + 1, np.uint64); offs[1:] = np.cumsum([len(e) for e in enc])
+            d_f = torch.from_numpy(np.concatenate(enc)).cuda()
+            d_r = torch.from_numpy(np.concatenate([e[::-1] for e in enc])).cuda()
+            d_o = torch.from_numpy(offs.view(np.int64)).cuda()
+            for name, ix in (("full", full), ("lean", lean)):
+                out = torch.empty(len(enc) * 4, dtype=torch.int32, device="cuda")
+                _lib.check(_lib.load().bwtgpu_search_reads(ix.h, d_f.data_ptr(), d_r.data_ptr(), d_o.data_ptr(),
+                                                           len(enc), anchor, out.data_ptr(), None))
+                assert np.array_equal(G.to_numpy_u32(out).reshape(-1, 4), want), f"search_reads {name} anchor={anchor}"
             full.close(); lean.close()
         except AssertionError as e:
             raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')}: {e}") from e
