@@ -253,7 +253,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return {"how": how, "wall_ms": float(tt.item()) * 1e3, "value": n / float(tt.item()) / 1e6,
                     "unit": "Mbp/s", "same_as_whole_build": bool(same),
-                    "what": "text replicated, one bucket range of the SA sorted per rank, shards broadcast "
+                    "what": "text replicated, one bucket range of the SA sorted per rank, shards all-gathered "
                             "over RCCL, every rank finishes its own index"}
         except Exception as e:  # noqa: BLE001 - the search figures do not depend on this
             return {"error": f"{type(e).__name__}: {e}"[:400]}

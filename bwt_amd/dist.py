@@ -6,9 +6,9 @@ caller asks for them on one rank.
 
 Suffix-array build: the text is replicated (a quarter byte per base), every
 rank sorts the suffixes of its own range of leading four-base strings -- a
-contiguous range of suffix-array rows -- and the shards are then broadcast into
-place, one collective per shard, so that every rank ends with the whole array
-and builds its own copy of the index.  Ids are never exchanged before the sort:
+contiguous range of suffix-array rows -- and the shards are then all-gathered
+into place, so that every rank ends with the whole array and builds its own
+copy of the index.  Ids are never exchanged before the sort:
 each rank reads its suffixes straight off its copy of the text, which costs
 less than moving four bytes per suffix over xGMI.
 
@@ -81,8 +81,8 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
     on every rank.  counts: the 256 bucket counts (same on every rank).
     build_range(lo, hi, rows_out, bw_out) -> (row_begin, rows, endloc) sorts one
     shard into the front of the two views it is given, or raises
-    NeedsWholeText.  Returns endloc.  Collectives: one broadcast per shard and
-    array, one 3-word all-reduce."""
+    NeedsWholeText.  Returns endloc.  Collectives: one 4-word all-reduce, then one
+    all-gather per array (or one broadcast per shard when shards are lopsided)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     ranges = plan_bucket_ranges(counts, world)
@@ -115,12 +115,39 @@ def build_sa_sharded(n, counts, build_range, sa, bw, group=None):
     if int(status[2]) != n:
         raise RuntimeError(f"shards hold {int(status[2])} rows, the text has {n} suffixes")
     sa[0] = n
+    _exchange_shards(sa, rows_of, rank, group)
+    _exchange_shards(bw, rows_of, rank, group)
+    return int(status[1])
+
+
+def _exchange_shards(arr, rows_of, rank, group):
+    """Every rank holds its own shard arr[begin:begin+rows]; afterwards all hold
+    all.  Shards of about equal size (the planned case) go through ONE all-gather
+    of shards padded to the longest -- a ring over xGMI moves it at full link
+    rate -- and are copied into place; lopsided ones (a bucket that outweighs a
+    share) are broadcast one by one so that no padding travels."""
+    world = len(rows_of)
+    longest = max(r for _, r in rows_of)
+    total = sum(r for _, r in rows_of)
+    if world > 1 and longest * world <= total + total // 4 + 1024:
+        begin, rows = rows_of[rank]
+        send = torch.empty(longest, dtype=arr.dtype, device=arr.device)
+        send[:rows] = arr[begin:begin + rows]
+        recv = torch.empty(longest * world, dtype=arr.dtype, device=arr.device)
+        if arr.is_cuda and _host_staged(group):
+            hs, hr = send.cpu(), torch.empty(longest * world, dtype=arr.dtype)
+            dist.all_gather_into_tensor(hr, hs, group=group)
+            recv.copy_(hr)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
+        for g, (b, r) in enumerate(rows_of):
+            if r and g != rank:
+                arr[b:b + r] = recv[g * longest:g * longest + r]
+        return
     for g, (b, r) in enumerate(rows_of):
         if r:
             src = dist.get_global_rank(group, g) if group is not None else g
-            _broadcast(sa[b:b + r], src, group)
-            _broadcast(bw[b:b + r], src, group)
-    return int(status[1])
+            _broadcast(arr[b:b + r], src, group)
 
 
 def search_sharded(R, search_slice, gather_to=None, group=None):

@@ -60,15 +60,19 @@ def _digits(bases, n):
     return ((padded[:-3] << 6) | (padded[1:-2] << 4) | (padded[2:-1] << 2) | padded[3:])[:n]
 
 
-def _worker(rank, world, port, n, R, m, fail_rank, q):
+def _worker(rank, world, port, n, R, m, fail_rank, q, skewed=False):
     try:
         from oracle import load_oracle
 
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         orc = load_oracle()
-        text = orc.gen_genome(n, synth.GENOME_SEED)
+        if skewed:  # one leading string outweighs a share: shards of very different sizes
+            rng = np.random.default_rng(11)
+            text = synth.pack(rng.choice(4, n, p=[0.91, 0.03, 0.03, 0.03]).astype(np.uint8))
+        else:
+            text = orc.gen_genome(n, synth.GENOME_SEED)
         bases = synth.unpack(text, n)
-        sa_o = orc.histsort(text, n)
+        sa_o = orc.sa_doubling(text, n) if skewed else orc.histsort(text, n)
         counts = np.bincount(_digits(bases, n), minlength=256).astype(np.uint64)
         bw_o = np.zeros(n + 1, np.uint8)
         nz = sa_o > 0
@@ -127,13 +131,15 @@ def _worker(rank, world, port, n, R, m, fail_rank, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fail_rank", [-1, 1])
-def test_two_ranks_over_gloo(fail_rank):
+@pytest.mark.parametrize("fail_rank,skewed", [(-1, False), (1, False), (-1, True)],
+                         ids=["even shards", "a rank needs the whole text", "lopsided shards"])
+def test_two_ranks_over_gloo(fail_rank, skewed):
     world, n, R, m = 2, 60000, 501, 24
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, m, fail_rank, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, R, m, fail_rank, q, skewed))
+             for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
