@@ -233,7 +233,7 @@ def main():
     located = int((pos != -1).sum().item())
 
     def sharded_build():
-        """HP1 sharded: one shard of the suffix array per rank, broadcast into place."""
+        """HP1 sharded: one shard of the suffix array per rank, all-gathered into place."""
         try:
             ixs, how = G.build_index_sharded(d_text, n)  # warm-up (workspace, RCCL channels)
             ixs.close()
