@@ -69,23 +69,21 @@ hipError_t pool_alloc(void **out, size_t bytes) {
 // The caller has made sure that no work in flight still uses the buffer.
 void pool_free(void *p) {
   if (!p) return;
-  Pooled item{p, 0, 0};
-  bool known = false, keep = false;
+  void *drop = p;  // what goes back to the driver: p itself unless the pool keeps it
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     auto it = g_live.find(p);
     if (it != g_live.end()) {
-      item = it->second;
+      g_idle.push_back(it->second);
       g_live.erase(it);
-      known = true;
-      if (g_idle.size() < kPoolMaxIdle) {
-        g_idle.push_back(item);
-        keep = true;
+      drop = nullptr;
+      if (g_idle.size() > kPoolMaxIdle) {  // the longest-idle buffer makes room
+        drop = g_idle.front().p;
+        g_idle.erase(g_idle.begin());
       }
     }
   }
-  (void)known;
-  if (!keep) (void)hipFree(p);
+  if (drop) (void)hipFree(drop);
 }
 
 void pool_release_idle() {
