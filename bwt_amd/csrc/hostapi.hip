@@ -6,10 +6,19 @@
 
 namespace bwtgpu {
 
+// A device buffer for the length of one host-form call.  The calls are
+// synchronous (every one ends with a blocking copy to the host), so by the time
+// a buffer goes back to the pool nothing is using it; repeated calls of one
+// size -- the scalar rank / lf / unc_sa of the reference API -- reuse it.
 struct Dev {
   void *p = nullptr;
-  ~Dev() { if (p) (void)hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 256); }
+  ~Dev() {
+    if (p) {
+      (void)hipDeviceSynchronize();
+      pool_free(p);
+    }
+  }
+  hipError_t alloc(size_t bytes) { return pool_alloc(&p, bytes ? bytes : 256); }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
