@@ -50,6 +50,7 @@ SIGNATURES = {
     "bwtgpu_lf_batch": (C.c_int, [vp, vp, u64, vp, vp]),
     "bwtgpu_sa_build_host": (C.c_int, [vp, u32, vp]),
     "bwtgpu_bwt_from_sa_host": (C.c_int, [vp, vp, u32, vp, vp]),
+    "bwtgpu_reverse_search_host": (C.c_int, [vp, vp, u32, u64, u64, vp]),
     "bwtgpu_search_host": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bwtgpu_locate_rows_host": (C.c_int, [vp, vp, u64, vp]),
     "bwtgpu_occ_host": (C.c_int, [vp, vp, vp, u64, C.c_int, vp]),

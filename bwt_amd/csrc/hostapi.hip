@@ -50,6 +50,16 @@ __global__ void k_lf_batch(IndexView v, const uint32_t *__restrict__ rows, uint6
   out[r] = i > v.n ? 0xFFFFFFFFu : lf_step(v, i);
 }
 
+// reverse_search's return value from the interval and the locate row
+// (seqindex.c:228-242): 0 if the interval emptied before the last step, else
+// ep - sp + 1 (sic).  Written over sp.
+__global__ void k_reverse_result(uint32_t *__restrict__ sp, const uint32_t *__restrict__ ep,
+                                 const uint32_t *__restrict__ locrow, uint64_t R) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  sp[r] = locrow[r] == 0xFFFFFFFFu ? 0u : ep[r] - sp[r] + 1u;
+}
+
 }  // namespace bwtgpu
 
 using namespace bwtgpu;
@@ -140,6 +150,35 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
     if (h_ep) BWT_HIP(hipMemcpy(h_ep + r0, ep.p, cnt * 4, hipMemcpyDeviceToHost));
     if (h_locrow) BWT_HIP(hipMemcpy(h_locrow + r0, lr.p, cnt * 4, hipMemcpyDeviceToHost));
     if (h_pos) BWT_HIP(hipMemcpy(h_pos + r0, pos.p, cnt * 4, hipMemcpyDeviceToHost));
+  }
+  return kOk;
+}
+
+// reverse_search for a batch: one int per read comes back instead of three
+int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride,
+                               uint64_t R, int32_t *h_result) {
+  if (!ix || !h_pats || !h_result || m == 0) return set_error(kErrArg, "bad argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint64_t chunk_max = stride ? (1ull << 30) / (stride > m ? stride : m) + 1 : R;
+  const uint64_t chunk = R < chunk_max ? R : chunk_max;
+  Dev pats, sp, ep, lr, ws;
+  const size_t wsb = bwtgpu_search_workspace_bytes(chunk, m);
+  hipError_t e = pats.alloc((chunk - 1) * stride + m + 64);
+  if (e == hipSuccess) e = sp.alloc(chunk * 4);
+  if (e == hipSuccess) e = ep.alloc(chunk * 4);
+  if (e == hipSuccess) e = lr.alloc(chunk * 4);
+  if (e == hipSuccess) e = ws.alloc(wsb);
+  if (e != hipSuccess) return set_error(kErrHip, "search buffers: %s", hipGetErrorString(e));
+  for (uint64_t r0 = 0; r0 < R; r0 += chunk) {
+    const uint64_t cnt = R - r0 < chunk ? R - r0 : chunk;
+    BWT_HIP(hipMemcpy(pats.p, h_pats + r0 * stride, (cnt - 1) * stride + m, hipMemcpyHostToDevice));
+    BWT_TRY(bwtgpu_search(ix, pats.as<uint8_t>(), m, stride, cnt, sp.as<uint32_t>(), ep.as<uint32_t>(),
+                          lr.as<uint32_t>(), ws.p, wsb, nullptr));
+    BWT_LAUNCH("reverse_result", k_reverse_result, dim3((unsigned)div_up(cnt, 256)), dim3(256), 0, nullptr,
+               sp.as<uint32_t>(), ep.as<uint32_t>(), lr.as<uint32_t>(), cnt);
+    BWT_CHECK_LAUNCH();
+    BWT_HIP(hipMemcpy(h_result + r0, sp.p, cnt * 4, hipMemcpyDeviceToHost));
   }
   return kOk;
 }

@@ -433,22 +433,13 @@ int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, lon
                              long nreads, int *result) {
   bwtgpu_index *ix = device_index(fmi);
   if (!ix) return -1;
-  uint32_t *sp = malloc((size_t)nreads * 4), *ep = malloc((size_t)nreads * 4);
-  int rc = -1;
-  /* result doubles as the buffer for the locate rows, which say whether the
-   * interval emptied before the last step */
-  if (sp && ep &&
-      !bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads, sp,
-                          ep, (uint32_t *)result, NULL)) {
-    for (long r = 0; r < nreads; ++r) /* seqindex.c:233-241 */
-      result[r] = (uint32_t)result[r] == 0xFFFFFFFFu ? 0 : (int)(ep[r] - sp[r] + 1);
-    rc = 0;
-  } else {
+  /* seqindex.c:233-241, evaluated on the device: one int per read comes back */
+  if (bwtgpu_reverse_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
+                                 (int32_t *)result)) {
     report("reverse_search");
+    return -1;
   }
-  free(sp);
-  free(ep);
-  return rc;
+  return 0;
 }
 
 int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,

@@ -213,6 +213,10 @@ int bwtgpu_bwt_from_sa_host(const uint8_t *h_text, const uint32_t *h_sa, uint32_
 int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m,
                        uint64_t stride, uint64_t R, uint32_t *h_sp, uint32_t *h_ep,
                        uint32_t *h_locrow, uint32_t *h_pos);
+/* reverse_search (seqindex.c:228-242) per read: 0 if the interval emptied before
+ * the last step, else ep - sp + 1 as the reference returns it */
+int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m,
+                               uint64_t stride, uint64_t R, int32_t *h_result);
 int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R,
                             uint32_t *h_pos);
 int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *h_idx,
