@@ -415,6 +415,11 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
 
 // ---- leaves ---------------------------------------------------------------
 
+constexpr int kLogLeafThreads = 9;
+constexpr int kLeafThreads = 1 << kLogLeafThreads;  // per leaf: eight waves, eight rows per thread
+constexpr int kLeafWaves = kLeafThreads / 64;
+constexpr int kLeafPer = kLeafMax / kLeafThreads;    // rows a thread owns, at most
+
 constexpr uint32_t kDeepRun = 8;     // tie runs up to this long are settled by direct comparison
 constexpr uint32_t kDeepWords = 32;  // ... over at most this many further 16-base words
 
@@ -436,14 +441,14 @@ __device__ __forceinline__ void cex(uint64_t &a, uint64_t &b, bool asc) {
   b = y;
 }
 
-// Bitonic sort of 256 << LOGE keys, 2^LOGE per thread, compare-exchanges done in
+// Bitonic sort of kLeafThreads << LOGE keys, 2^LOGE per thread, compare-exchanges done in
 // registers: a stage whose stride bit lies outside the bits a thread holds
 // costs one trip through LDS that re-deals the elements, and each trip then
 // serves up to LOGE stages.  Ends in the blocked layout.
 template <int LOGE>
 __device__ __forceinline__ void leaf_bitonic(uint64_t (&r)[1 << LOGE], uint64_t *lds, uint32_t t) {
   constexpr int E = 1 << LOGE;
-  constexpr int LOGP = LOGE + 8;
+  constexpr int LOGP = LOGE + kLogLeafThreads;
 #pragma unroll
   for (int lk = 1; lk <= LOGE; ++lk) {
 #pragma unroll
@@ -529,13 +534,13 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
                                                  const uint32_t *__restrict__ srckey, uint32_t start,
                                                  uint32_t size, uint32_t depth, uint64_t *lds,
                                                  uint32_t *cnt, uint32_t *red, uint32_t t) {
-  constexpr int E = kLeafMax / 256;
+  constexpr int E = kLeafPer;
   const uint32_t lane = t & 63u, wave = t >> 6;
   uint64_t r[E];
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
 #pragma unroll
   for (int m = 0; m < E; ++m) {
-    const uint32_t j = (uint32_t)m * 256 + t;
+    const uint32_t j = (uint32_t)m * kLeafThreads + t;
     r[m] = ~0ull;
     if (j < size) {
       r[m] = leaf_fetch(tb, src, srckey, start + j, depth);
@@ -545,7 +550,7 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
     }
   }
 #pragma unroll
-  for (int q = 0; q < (int)(kLeafBuckets / 512); ++q) cnt[q * 256 + t] = 0;
+  for (int q = 0; q < (int)(kLeafBuckets / 2 / kLeafThreads); ++q) cnt[q * kLeafThreads + t] = 0;
   for (int off = 32; off; off >>= 1) {
     const uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
     kmin = a < kmin ? a : kmin;
@@ -553,18 +558,18 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
   }
   if (lane == 0) {
     red[wave] = kmin;
-    red[4 + wave] = kmax;
+    red[kLeafWaves + wave] = kmax;
   }
   __syncthreads();
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < kLeafWaves; ++w) {
     kmin = red[w] < kmin ? red[w] : kmin;
-    kmax = red[4 + w] > kmax ? red[4 + w] : kmax;
+    kmax = red[kLeafWaves + w] > kmax ? red[kLeafWaves + w] : kmax;
   }
   const float scale = (float)kLeafBuckets / (float)(kmax - kmin + 1u);
   uint32_t bucket[E], slot[E];
 #pragma unroll
   for (int m = 0; m < E; ++m) {
-    const uint32_t j = (uint32_t)m * 256 + t;
+    const uint32_t j = (uint32_t)m * kLeafThreads + t;
     if (j < size) {
       uint32_t b = (uint32_t)((float)(word_key(r[m]) - kmin) * scale);
       b = b < kLeafBuckets ? b : kLeafBuckets - 1;
@@ -575,7 +580,7 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
   }
   __syncthreads();
   // exclusive scan of the bucket counts; thread t owns buckets [B t, B t + B)
-  constexpr int B = kLeafBuckets / 256;
+  constexpr int B = kLeafBuckets / kLeafThreads;
   uint32_t own[B], sum = 0, fullest = 0;
 #pragma unroll
   for (int q = 0; q < B; ++q) {
@@ -594,13 +599,12 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
   }
   __syncthreads();  // red[] is read by every thread above before it is reused
   if (lane == 63) red[wave] = v;
-  if (lane == 0) red[4 + wave] = fullest;
+  if (lane == 0) red[kLeafWaves + wave] = fullest;
   __syncthreads();
   uint32_t first = v - sum;
   for (uint32_t w = 0; w < wave; ++w) first += red[w];
-  fullest = red[4] > red[5] ? red[4] : red[5];
-  fullest = red[6] > fullest ? red[6] : fullest;
-  fullest = red[7] > fullest ? red[7] : fullest;
+  fullest = 0;
+  for (int w = 0; w < kLeafWaves; ++w) fullest = red[kLeafWaves + w] > fullest ? red[kLeafWaves + w] : fullest;
   if (fullest > kLeafBucketMax) return false;
   {
     uint32_t run = first;
@@ -613,7 +617,7 @@ __device__ __forceinline__ bool leaf_bucket_sort(const uint32_t *__restrict__ tb
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < E; ++m) {
-    const uint32_t j = (uint32_t)m * 256 + t;
+    const uint32_t j = (uint32_t)m * kLeafThreads + t;
     if (j < size) lds[pad(((cnt[bucket[m] >> 1] >> (16 * (bucket[m] & 1u))) & 0xFFFFu) + slot[m])] = r[m];
   }
   __syncthreads();
@@ -657,7 +661,7 @@ __device__ __forceinline__ int deep_cmp(const uint32_t *__restrict__ tb, uint32_
 // descending), settles short runs of equal keys by comparing the suffixes
 // further, writes the rows of the suffix array, and records for every row the
 // first row of its tie group (its own row when resolved).
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(kLeafThreads, 2)
 k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
             const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
@@ -666,8 +670,8 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             Counters *__restrict__ ctr) {
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
-  __shared__ uint32_t wred[4], wmax[4];
-  __shared__ uint32_t bcnt[kLeafBuckets / 2], bred[8];
+  __shared__ uint32_t wred[kLeafWaves], wmax[kLeafWaves];
+  __shared__ uint32_t bcnt[kLeafBuckets / 2], bred[2 * kLeafWaves];
   const Leaf lf = leaves[blockIdx.x];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t srcid = lf.src & 255u, keybases = lf.src >> 8;
@@ -687,23 +691,21 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   if (t < kLeafMax / 32) settled[t] = 0;
   uint32_t P = 2;
   while (P < size) P <<= 1;
-  if (size > 256 && leaf_bucket_sort(tb, src, srckey, start, size, depth, keys, bcnt, bred, t)) {
+  if (size > kLeafThreads && leaf_bucket_sort(tb, src, srckey, start, size, depth, keys, bcnt, bred, t)) {
     // sorted by the counting pass
-  } else if (P == 4096) {
-    leaf_load_sort<4>(tb, src, srckey, start, size, depth, keys, t);
-  } else if (P == 2048) {
+  } else if (kLeafPer >= 8 && P == 8 * kLeafThreads) {
     leaf_load_sort<3>(tb, src, srckey, start, size, depth, keys, t);
-  } else if (P == 1024) {
+  } else if (kLeafPer >= 4 && P == 4 * kLeafThreads) {
     leaf_load_sort<2>(tb, src, srckey, start, size, depth, keys, t);
-  } else if (P == 512) {
+  } else if (P == 2 * kLeafThreads) {
     leaf_load_sort<1>(tb, src, srckey, start, size, depth, keys, t);
   } else {
-    for (uint32_t j = t; j < P; j += 256)
+    for (uint32_t j = t; j < P; j += kLeafThreads)
       keys[pad(j)] = j < size ? leaf_fetch(tb, src, srckey, start + j, depth) : ~0ull;
     __syncthreads();
     for (uint32_t k = 2; k <= P; k <<= 1) {
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t q = t; q < (P >> 1); q += 256) {
+        for (uint32_t q = t; q < (P >> 1); q += kLeafThreads) {
           const uint32_t i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
           const uint32_t x = i | j;
           const uint64_t a = keys[pad(i)], b = keys[pad(x)];
@@ -718,14 +720,14 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   }
   __syncthreads();
   // blocked from here on: thread t owns rows [t*per, t*per+per)
-  const uint32_t per = (P + 255) / 256;  // 1..16
+  const uint32_t per = (P + kLeafThreads - 1) / kLeafThreads;  // 1..kLeafPer
   const uint32_t j0 = t * per;
   // the thread's rows and one neighbour on each side, in registers: w[1 + k] is
   // row j0 + k
-  uint64_t w[18];
+  uint64_t w[kLeafPer + 2];
   auto load_window = [&]() {
 #pragma unroll
-    for (uint32_t k = 0; k < 18; ++k) {
+    for (uint32_t k = 0; k < kLeafPer + 2; ++k) {
       const uint32_t j = j0 + k - 1u;  // wraps below row 0, which then fails j < size
       w[k] = (k <= per + 1 && j < size) ? keys[pad(j)] : ~0ull;
     }
@@ -733,14 +735,14 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   load_window();
   bool any_equal = false;
 #pragma unroll
-  for (uint32_t k = 0; k < 17; ++k) {
+  for (uint32_t k = 0; k < kLeafPer + 1; ++k) {
     const uint32_t j = j0 + k - 1u;  // rows j and j + 1
     any_equal = any_equal || (k <= per && j < size && j + 1 < size && word_key(w[k]) == word_key(w[k + 1]));
   }
   // equal keys are rare (none in most leaves of a random text): only then are
   // runs settled by deeper comparison, in LDS, and the window read again
   const bool ties = __syncthreads_or(any_equal);  // also: every thread has read its window
-  uint64_t outv[16];
+  uint64_t outv[kLeafPer];
   if (ties) {
     // short runs of equal keys: the thread that owns the first row of a run
     // orders the whole run by comparing the suffixes beyond the key
@@ -771,10 +773,10 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     }
     __syncthreads();
     load_window();
-    uint32_t hv[16];
+    uint32_t hv[kLeafPer];
     uint32_t local_max = 0, tied_rows = 0;
   #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
+    for (uint32_t k = 0; k < kLeafPer; ++k) {
       hv[k] = 0;
       const uint32_t j = j0 + k;
       if (k < per && j < size) {
@@ -817,7 +819,8 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     const uint32_t up = __shfl_up(v, 1, 64);
     if (lane) before = up > before ? up : before;
     if (t == 0) {
-      const uint32_t total = wred[0] + wred[1] + wred[2] + wred[3];
+      uint32_t total = 0;
+      for (int q = 0; q < kLeafWaves; ++q) total += wred[q];
       if (total) {
         atomicAdd(&ctr->unresolved, total);
         atomicMin(&ctr->min_depth, depth + keybases);
@@ -826,7 +829,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     // every thread has read its neighbours' keys; now reuse the LDS slots
     uint32_t run = before;
   #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
+    for (uint32_t k = 0; k < kLeafPer; ++k) {
       const uint32_t j = j0 + k;
       if (k < per && j < size) {
         const uint64_t cur = w[k + 1];
@@ -841,7 +844,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   } else {
     // no two neighbouring keys are equal: every row is its own group
 #pragma unroll
-    for (uint32_t k = 0; k < 16; ++k) {
+    for (uint32_t k = 0; k < kLeafPer; ++k) {
       const uint32_t j = j0 + k;
       if (k < per && j < size) {
         const uint64_t cur = w[k + 1];
@@ -852,12 +855,12 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     }
   }
 #pragma unroll
-  for (uint32_t k = 0; k < 16; ++k) {
+  for (uint32_t k = 0; k < kLeafPer; ++k) {
     const uint32_t j = j0 + k;
     if (k < per && j < size) keys[pad(j)] = outv[k];
   }
   __syncthreads();
-  for (uint32_t j = t; j < size; j += 256) {
+  for (uint32_t j = t; j < size; j += kLeafThreads) {
     const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
     ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
@@ -1237,7 +1240,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   g_stats.v[1] = nleaves_host;
   g_stats.v[4] = depth;
   if (nleaves_host)
-    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(256), 0, s, tb, bufA, bufB, keyA, keyB,
+    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
                leaves, n, bufA, ghead, bw, ctr);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
