@@ -173,14 +173,19 @@ __global__ void __launch_bounds__(kPartThreads)
 k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
             const uint32_t *__restrict__ srckey, const Seg *__restrict__ segs,
             const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
-            const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
+            const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts, int by_eighth) {
+  // by_eighth (level 0, one segment): counts are kept per eighth of the tiles,
+  // the share one XCD's scatter workgroups handle (see locate_tile), in slot
+  // `eighth` where a segment number goes otherwise.
   __shared__ uint32_t hist[256];
   __shared__ TileInfo ti;
   hist[threadIdx.x] = 0;
   uint32_t cur_seg = 0xFFFFFFFFu;
+  const uint32_t per_xcd = (ctr->total_tiles + 7u) / 8u;
   for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
-    const bool live = locate_tile_at(blockIdx.x * kHistTilesPerGroup + k, segs, tile_first, nsegs, ctr, &ti);
-    const uint32_t seg = live ? ti.seg : 0xFFFFFFFFu;
+    const uint32_t tile = blockIdx.x * kHistTilesPerGroup + k;
+    const bool live = locate_tile_at(tile, segs, tile_first, nsegs, ctr, &ti);
+    const uint32_t seg = !live ? 0xFFFFFFFFu : by_eighth ? tile / per_xcd : ti.seg;
     if (seg != cur_seg) {
       if (cur_seg != 0xFFFFFFFFu) {
         const uint32_t c = hist[threadIdx.x];
@@ -224,11 +229,19 @@ __global__ void __launch_bounds__(256)
 k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
                 uint32_t dst_id /* leaf_src_word */, Seg *__restrict__ next_segs, uint32_t next_cap,
                 Leaf *__restrict__ leaves, uint32_t leaf_cap, uint32_t *__restrict__ leafmask,
-                Counters *__restrict__ ctr) {
+                Counters *__restrict__ ctr, int by_eighth) {
+  // by_eighth (level 0, one segment): seg_counts holds eight rows of counts, one
+  // per eighth of the tiles; each becomes that eighth's own run of cursors
+  // inside every child, so that what one XCD scatters lies together.
   __shared__ uint32_t sizes[256], starts[256], wsum[4];
   const uint32_t s = blockIdx.x, t = threadIdx.x;
   const Seg sg = segs[s];
-  const uint32_t c = seg_counts[(uint64_t)s * 256 + t];
+  uint32_t c = 0;
+  if (by_eighth) {
+    for (int e = 0; e < 8; ++e) c += seg_counts[e * 256 + t];
+  } else {
+    c = seg_counts[(uint64_t)s * 256 + t];
+  }
   uint32_t v = c;
   const uint32_t lane = t & 63u, wave = t >> 6;
   for (int off = 1; off < 64; off <<= 1) {
@@ -240,7 +253,16 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   uint32_t pre = 0;
   for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
   const uint32_t start = sg.start + pre + v - c;
-  seg_counts[(uint64_t)s * 256 + t] = start;  // becomes the scatter cursor
+  if (by_eighth) {
+    uint32_t run = start;
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t part = seg_counts[e * 256 + t];
+      seg_counts[e * 256 + t] = run;
+      run += part;
+    }
+  } else {
+    seg_counts[(uint64_t)s * 256 + t] = start;  // becomes the scatter cursor
+  }
   sizes[t] = c;
   starts[t] = start;
   {
@@ -291,16 +313,19 @@ __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
 // Sharded build, level 0: keeps the counts of the digits in [dlo, dhi), clears
 // the others, and reports how many suffixes precede the range and fall in it.
 __global__ void __launch_bounds__(256)
-k_restrict_level0(uint32_t *__restrict__ counts, uint32_t dlo, uint32_t dhi,
-                  uint64_t *__restrict__ out /* [0] before, [1] inside */) {
+k_restrict_level0(uint32_t *__restrict__ counts /* [8][256], one row per eighth of the tiles */,
+                  uint32_t dlo, uint32_t dhi, uint64_t *__restrict__ out /* [0] before, [1] inside */) {
   __shared__ unsigned long long before, inside;
   const uint32_t t = threadIdx.x;
   if (t == 0) before = inside = 0;
   __syncthreads();
-  const uint32_t c = counts[t];
+  uint32_t c = 0;
+  for (int e = 0; e < 8; ++e) {
+    c += counts[e * 256 + t];
+    if (t < dlo || t >= dhi) counts[e * 256 + t] = 0;
+  }
   if (t < dlo) atomicAdd(&before, (unsigned long long)c);
   else if (t < dhi) atomicAdd(&inside, (unsigned long long)c);
-  if (t < dlo || t >= dhi) counts[t] = 0;
   __syncthreads();
   if (t == 0) {
     out[0] = before;
@@ -390,7 +415,9 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
     lstart[t] = pre + v - c;
-    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+    // level 0 keeps one row of cursors per eighth of the tiles, i.e. per XCD
+    const uint64_t cursor_row = IMPLICIT ? (uint64_t)(blockIdx.x & 7u) : (uint64_t)ti.seg;
+    gbase[t] = c ? atomicAdd(&cursors[cursor_row * 256 + t], c) : 0u;
   }
   __syncthreads();
 #pragma unroll
@@ -1171,27 +1198,27 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                segs[cur], nsegs, tile_first);
     BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tile_first, tile_first, nsegs, &ctr->total_tiles,
                             scanws, scanws_bytes, s));
-    BWT_HIP(hipMemsetAsync(counts, 0, (size_t)nsegs * 256 * 4, s));
+    const bool implicit = src_id == kSrcImplicit;  // level 0: one segment, counts per eighth of its tiles
+    BWT_HIP(hipMemsetAsync(counts, 0, (size_t)(implicit ? 8 : nsegs) * 256 * 4, s));
     BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
     const unsigned tile_bound = (unsigned)(((uint64_t)n / kPartTile + nsegs + 1 + 7) / 8 * 8);  // eighths, see locate_tile
     const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
     const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_hist", k_part_hist<0>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 1);
     } else if (levels == 1) {
       // level 0 stored words that start with this level's four bases
       BWT_LAUNCH("sa_part_hist", k_part_hist<3>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 0);
     } else {
       // the word stored by the previous level holds this level's four bases in its second byte
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 0);
     }
     // Without a gather a suffix that ends in a leaf keeps bases [depth, reach) as
     // its sort key, and one that goes on needs the next level's digit, bases
     // [depth + 4, depth + 8).  Level 0 always reads the text.
-    const bool implicit = src_id == kSrcImplicit;
     const bool gather_all = !implicit && (reach < depth + 11 || reach < depth + 2 * kDigitBases);
     const uint32_t leaf_keybases = (implicit || gather_all) ? kLeafKeyBases : reach - depth;
     if (range && depth == 0) {
@@ -1213,7 +1240,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
-               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr);
+               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kScatThreads), 0, s, tb,
                  src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, 0, dlo,
