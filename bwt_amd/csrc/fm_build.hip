@@ -107,118 +107,87 @@ __global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
 // position -- bin b owns positions [b << shift, (b+1) << shift), so its pairs
 // fill exactly that range of the pair buffer and no counting pass is needed --
 // then the bins are emptied in order.
-constexpr int kIsaTile = 4096;
+constexpr int kIsaThreads = 512;
+constexpr int kIsaItems = 16;
+constexpr int kIsaTile = kIsaThreads * kIsaItems;  // 8192 pairs: 32-pair (256-byte) runs per bin
 
-__global__ void __launch_bounds__(256)
-k_isa_partition(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t shift,
-                unsigned long long *__restrict__ cursors /* [256], start at b << shift */,
-                uint64_t *__restrict__ pairs) {
-  __shared__ uint32_t hist[256], lstart[256], fill[256], wsum[4];
-  __shared__ unsigned long long gbase[256];
-  __shared__ uint64_t stage[kIsaTile];
-  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const uint64_t row0 = (uint64_t)blockIdx.x * kIsaTile;
-  hist[t] = 0;
-  fill[t] = 0;
-  __syncthreads();
-  uint32_t id[kIsaTile / 256];
-#pragma unroll
-  for (int i = 0; i < kIsaTile / 256; ++i) {
-    const uint64_t row = row0 + (uint64_t)i * 256 + t;
-    id[i] = row < rows ? sa[row] : 0xFFFFFFFFu;
-    if (row < rows) atomicAdd(&hist[id[i] >> shift], 1u);
-  }
-  __syncthreads();
-  const uint32_t c = hist[t];
-  uint32_t v = c;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  uint32_t pre = 0;
-  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
-  lstart[t] = pre + v - c;
-  gbase[t] = c ? atomicAdd(&cursors[t], (unsigned long long)c) : 0ull;
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < kIsaTile / 256; ++i) {
-    const uint64_t row = row0 + (uint64_t)i * 256 + t;
-    if (row < rows) {
-      const uint32_t b = id[i] >> shift;
-      stage[lstart[b] + atomicAdd(&fill[b], 1u)] = ((uint64_t)row << 32) | id[i];
-    }
-  }
-  __syncthreads();
-  const uint32_t placed = lstart[255] + hist[255];
-  for (uint32_t j = t; j < placed; j += 256) {
-    const uint64_t pr = stage[j];
-    const uint32_t b = (uint32_t)pr >> shift;
-    pairs[gbase[b] + (j - lstart[b])] = pr;
-  }
+__global__ void k_isa_cursors1(uint32_t shift, unsigned long long *__restrict__ cursors) {
+  cursors[threadIdx.x] = (unsigned long long)threadIdx.x << shift;  // bin b starts at slot b << shift
 }
 
 // Second level for large arrays: the pairs of each first-level bin (a run of
 // 1 << shift1 slots, tiles never straddle two) are dealt into 256 sub-bins by the
 // next eight bits of the position; sub-bin (b, c) owns slots
 // [(b << shift1) + (c << shift2), ...) of the output.
-__global__ void k_isa_cursors1(uint32_t shift, unsigned long long *__restrict__ cursors) {
-  cursors[threadIdx.x] = (unsigned long long)threadIdx.x << shift;  // bin b starts at slot b << shift
-}
-
 __global__ void k_isa_cursors2(uint32_t shift1, uint32_t shift2, unsigned long long *__restrict__ cursors) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // 65536 of them
   cursors[i] = ((unsigned long long)(i >> 8) << shift1) + ((unsigned long long)(i & 255u) << shift2);
 }
 
-__global__ void __launch_bounds__(256)
-k_isa_partition2(const uint64_t *__restrict__ in, uint64_t rows, uint32_t shift1, uint32_t shift2,
-                 unsigned long long *__restrict__ cursors /* [256][256] */, uint64_t *__restrict__ out) {
+// One tile of pairs into its 256 bins: tile-local bin order in LDS, one cursor
+// claim per (tile, bin), runs written out whole.
+// LEVEL 1: the tile is kIsaTile rows of the suffix array, bin = position >> shift,
+//          cursors[256].
+// LEVEL 2: the tile is kIsaTile pairs of one first-level bin (row0 >> shift1),
+//          bin = (position >> shift) & 255, cursors[256][256].
+template <int LEVEL>
+__global__ void __launch_bounds__(kIsaThreads)
+k_isa_deal(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ in, uint64_t rows, uint32_t shift1,
+           uint32_t shift, unsigned long long *__restrict__ cursors, uint64_t *__restrict__ out) {
   __shared__ uint32_t hist[256], lstart[256], fill[256], wsum[4];
   __shared__ unsigned long long gbase[256];
   __shared__ uint64_t stage[kIsaTile];
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint64_t row0 = (uint64_t)blockIdx.x * kIsaTile;
-  const uint32_t bin1 = (uint32_t)(row0 >> shift1);
-  hist[t] = 0;
-  fill[t] = 0;
-  __syncthreads();
-  uint64_t pr[kIsaTile / 256];
-#pragma unroll
-  for (int i = 0; i < kIsaTile / 256; ++i) {
-    const uint64_t j = row0 + (uint64_t)i * 256 + t;
-    pr[i] = j < rows ? in[j] : 0ull;
-    if (j < rows) atomicAdd(&hist[((uint32_t)pr[i] >> shift2) & 255u], 1u);
+  unsigned long long *cur = LEVEL == 1 ? cursors : cursors + (row0 >> shift1) * 256u;
+  if (t < 256) {
+    hist[t] = 0;
+    fill[t] = 0;
   }
   __syncthreads();
-  const uint32_t c = hist[t];
-  uint32_t v = c;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t u = __shfl_up(v, off, 64);
-    if (lane >= off) v += u;
-  }
-  if (lane == 63) wsum[wave] = v;
-  __syncthreads();
-  uint32_t pre = 0;
-  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
-  lstart[t] = pre + v - c;
-  gbase[t] = c ? atomicAdd(&cursors[bin1 * 256u + t], (unsigned long long)c) : 0ull;
-  __syncthreads();
+  uint64_t pr[kIsaItems];
 #pragma unroll
-  for (int i = 0; i < kIsaTile / 256; ++i) {
-    const uint64_t j = row0 + (uint64_t)i * 256 + t;
+  for (int i = 0; i < kIsaItems; ++i) {
+    const uint64_t j = row0 + (uint64_t)i * kIsaThreads + t;
+    pr[i] = 0;
     if (j < rows) {
-      const uint32_t b = ((uint32_t)pr[i] >> shift2) & 255u;
+      pr[i] = LEVEL == 1 ? ((uint64_t)j << 32) | sa[j] : in[j];
+      atomicAdd(&hist[((uint32_t)pr[i] >> shift) & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t c = 0, v = 0;
+  if (t < 256) {
+    c = hist[t];
+    v = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+  }
+  __syncthreads();
+  if (t < 256) {
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+    lstart[t] = pre + v - c;
+    gbase[t] = c ? atomicAdd(&cur[t], (unsigned long long)c) : 0ull;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kIsaItems; ++i) {
+    const uint64_t j = row0 + (uint64_t)i * kIsaThreads + t;
+    if (j < rows) {
+      const uint32_t b = ((uint32_t)pr[i] >> shift) & 255u;
       stage[lstart[b] + atomicAdd(&fill[b], 1u)] = pr[i];
     }
   }
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
-  for (uint32_t j = t; j < placed; j += 256) {
+  for (uint32_t j = t; j < placed; j += kIsaThreads) {
     const uint64_t p = stage[j];
-    const uint32_t b = ((uint32_t)p >> shift2) & 255u;
-    out[gbase[b] + (j - lstart[b])] = p;
+    const uint32_t bin = ((uint32_t)p >> shift) & 255u;
+    out[gbase[bin] + (j - lstart[bin])] = p;
   }
 }
 
@@ -257,19 +226,19 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   unsigned long long *d_cur = reinterpret_cast<unsigned long long *>(scratch);
   uint64_t *pairs = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(scratch) + 2048);
   BWT_LAUNCH("isa_cursors", k_isa_cursors1, dim3(1), dim3(256), 0, s, shift, d_cur);
-  BWT_LAUNCH("isa_partition", k_isa_partition, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s, d_sa,
-             rows, shift, d_cur, pairs);
+  BWT_LAUNCH("isa_partition", k_isa_deal<1>, dim3((unsigned)div_up(rows, kIsaTile)), dim3(kIsaThreads), 0, s,
+             d_sa, (const uint64_t *)nullptr, rows, 0u, shift, d_cur, pairs);
   const uint64_t *filled = pairs;
   uint32_t window_shift = shift;
   uint64_t *pairs2 = nullptr;
   unsigned long long *d_cur2 = nullptr;
-  if (((4ull << shift) > (2ull << 20) || force2) && shift >= 12) {
+  if (((4ull << shift) > (2ull << 20) || force2) && shift >= 13) {  // tiles of 2^13 pairs must not straddle bins
     // windows beyond an L2: split each bin once more, if there is room for a second pair buffer
     if (pool_alloc(&pairs2, rows * 8) == hipSuccess && pool_alloc(&d_cur2, 65536 * 8) == hipSuccess) {
       const uint32_t shift2 = shift - 8;
       BWT_LAUNCH("isa_cursors2", k_isa_cursors2, dim3(256), dim3(256), 0, s, shift, shift2, d_cur2);
-      BWT_LAUNCH("isa_partition2", k_isa_partition2, dim3((unsigned)div_up(rows, kIsaTile)), dim3(256), 0, s,
-                 pairs, rows, shift, shift2, d_cur2, pairs2);
+      BWT_LAUNCH("isa_partition2", k_isa_deal<2>, dim3((unsigned)div_up(rows, kIsaTile)), dim3(kIsaThreads), 0, s,
+                 (const uint32_t *)nullptr, pairs, rows, shift, shift2, d_cur2, pairs2);
       filled = pairs2;
       window_shift = shift2;
     } else {
