@@ -694,6 +694,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
             uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
             uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
+            uint8_t *__restrict__ leaf_ties /* per leaf: 1 if it wrote tie-group heads */,
             Counters *__restrict__ ctr) {
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
@@ -709,7 +710,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
       const uint64_t w = leaf_fetch(tb, src, srckey, start, depth);
       const uint32_t id = word_id(w);
       sa_rows[start] = id;
-      ghead[1 + start] = 1 + start;
+      leaf_ties[blockIdx.x] = 0;
       bw[start] = (uint8_t)(w & 3u);
       if (id == 0) ctr->endloc = 1 + start;
     }
@@ -887,12 +888,23 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     if (k < per && j < size) keys[pad(j)] = outv[k];
   }
   __syncthreads();
+  if (t == 0) leaf_ties[blockIdx.x] = ties ? 1 : 0;
   for (uint32_t j = t; j < size; j += kLeafThreads) {
     const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
-    ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
+    // heads matter to prefix doubling only; a leaf without ties leaves them to k_ghead_identity
+    if (ties) ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
     bw[start + j] = (uint8_t)(o >> 44);
   }
+}
+
+// Before prefix doubling: every row of a leaf that found no ties is its own group.
+__global__ void __launch_bounds__(256)
+k_ghead_identity(const Leaf *__restrict__ leaves, const uint8_t *__restrict__ leaf_ties,
+                 uint32_t *__restrict__ ghead) {
+  if (leaf_ties[blockIdx.x]) return;
+  const Leaf lf = leaves[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < lf.size; j += 256) ghead[1 + lf.start + j] = 1 + lf.start + j;
 }
 
 // Segments still above kLeafMax when the bucket levels stop: one tie group
@@ -1082,7 +1094,7 @@ static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0,
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, ctr, scanws, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, ctr, scanws, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -1110,6 +1122,7 @@ static Layout layout_for(uint32_t n) {
   L.leafmask = take((size_t)L.seg_cap * 8 * 4);
   L.tile_first = take(((size_t)L.seg_cap + 1) * 4);
   L.leaves = take((size_t)L.leaf_cap * sizeof(Leaf));
+  L.leaf_ties = take((size_t)L.leaf_cap);
   L.ctr = take(sizeof(Counters));
   L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
   L.end = off;
@@ -1159,6 +1172,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   uint32_t *leafmask = reinterpret_cast<uint32_t *>(ws + L.leafmask);
   uint32_t *tile_first = reinterpret_cast<uint32_t *>(ws + L.tile_first);
   Leaf *leaves = reinterpret_cast<Leaf *>(ws + L.leaves);
+  uint8_t *leaf_ties = ws + L.leaf_ties;
   Counters *ctr = reinterpret_cast<Counters *>(ws + L.ctr);
   void *scanws = ws + L.scanws;
   const size_t scanws_bytes = scan_workspace_bytes(L.seg_cap + 1);
@@ -1268,7 +1282,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   g_stats.v[4] = depth;
   if (nleaves_host)
     BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
-               leaves, n, bufA, ghead, bw, ctr);
+               leaves, n, bufA, ghead, bw, leaf_ties, ctr);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
     BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
@@ -1293,6 +1307,9 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   }
   if (h_ctr.unresolved) {
     // bufB is free from here on: reuse it for the active-row flags
+    if (nleaves_host)
+      BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(nleaves_host), dim3(256), 0, s, leaves, leaf_ties,
+                 ghead);
     BWT_TRY(sa_doubling(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
   }
   return kOk;
