@@ -51,25 +51,34 @@ k_emit_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa,
 // Same, when the suffix-array build left the BWT symbol of every row behind
 // (bw[r-1] for row r >= 1): a streaming pass, no gather.  Row 0 is the $ suffix,
 // preceded by the last base of the text.
+constexpr int kPlanesPerWave = 8;  // blocks one wave emits: its loads are issued together
+
 __global__ void __launch_bounds__(256)
 k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__ bw, uint32_t n,
                    const uint32_t *__restrict__ d_endloc, IndexBlock *__restrict__ blocks,
                    uint64_t nblocks) {
-  const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t b0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kPlanesPerWave;
   const uint32_t lane = threadIdx.x & 63u;
-  if (b >= nblocks) return;  // wave-uniform
+  if (b0 >= nblocks) return;  // wave-uniform
   const uint32_t endloc = *d_endloc;
-  const uint64_t p = b * 64 + lane;
-  uint32_t base = 0;
-  if (p < n) {
-    const uint64_t row = p + (p >= endloc ? 1 : 0);
-    base = row ? bw[row - 1] : text_base(text, (uint64_t)n - 1);
+  uint32_t base[kPlanesPerWave];
+#pragma unroll
+  for (int k = 0; k < kPlanesPerWave; ++k) {
+    const uint64_t p = (b0 + k) * 64 + lane;
+    base[k] = 0;
+    if (p < n) {
+      const uint64_t row = p + (p >= endloc ? 1 : 0);
+      base[k] = row ? bw[row - 1] : text_base(text, (uint64_t)n - 1);
+    }
   }
-  const uint64_t lo = __ballot(base & 1u);
-  const uint64_t hi = __ballot(base & 2u);
-  if (lane == 0) {
-    blocks[b].lo = lo;
-    blocks[b].hi = hi;
+#pragma unroll
+  for (int k = 0; k < kPlanesPerWave; ++k) {
+    const uint64_t lo = __ballot(base[k] & 1u);
+    const uint64_t hi = __ballot(base[k] & 2u);
+    if (lane == 0 && b0 + k < nblocks) {
+      blocks[b0 + k].lo = lo;
+      blocks[b0 + k].hi = hi;
+    }
   }
 }
 
@@ -369,7 +378,8 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
                       const uint8_t *bw, uint32_t *d_endloc, void *isa_scratch, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
-    BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows, dim3((unsigned)div_up(ix->nblocks * 64, 256)),
+    BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows,
+               dim3((unsigned)div_up(div_up(ix->nblocks, kPlanesPerWave) * 64, 256)),
                dim3(256), 0, s, d_text, bw, n, d_endloc, ix->d_blocks, ix->nblocks);
   } else {
     (void)hipMemsetAsync(d_endloc, 0xFF, 4, s);
