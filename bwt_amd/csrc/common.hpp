@@ -169,6 +169,10 @@ int index_alloc(bwtgpu_index **out, uint32_t n);
 struct SaExtras {
   const uint8_t *bw = nullptr;
   const uint32_t *endloc = nullptr;
+  // in: where the leaf sort may drop every 8th row as it writes it (SA[8 i] at
+  // samples[i]), or null; out: whether all of them were written
+  uint32_t *samples = nullptr;
+  bool samples_done = false;
 };
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
                   size_t ws_bytes, hipStream_t s, SaExtras *extras);

@@ -375,7 +375,8 @@ static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
 // ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
 // rows 1..n and *d_endloc then already holds the $ row.
 static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
-                      const uint8_t *bw, uint32_t *d_endloc, void *isa_scratch, hipStream_t s) {
+                      const uint8_t *bw, uint32_t *d_endloc, void *isa_scratch, bool have_samples,
+                      hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
     BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows,
@@ -389,7 +390,8 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
                d_text, d_sa, n, d_endloc, ix->d_blocks, ix->nblocks);
   }
   const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
-  BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
+  if (!have_samples)  // else the leaf sort dropped them as it wrote the rows
+    BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
   if (ix->d_sa) {
     BWT_TRY(inverse_suffix_array(d_sa, n, ix->d_isa, isa_scratch, s));
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
@@ -417,11 +419,13 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   uint32_t *d_sa = ix->d_sa ? ix->d_sa : reinterpret_cast<uint32_t *>(g_cache.sa);
   uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
   SaExtras extras;
+  extras.samples = ix->d_idxs;
   rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
     if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
     // the sort's id and key buffers (12 bytes per row, contiguous) are free again
-    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, sa_workspace_free_region(n, g_cache.ws), s);
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, sa_workspace_free_region(n, g_cache.ws),
+                    extras.samples_done, s);
   }
   if (rc != kOk) {
     bwtgpu_index_free(ix);
@@ -545,7 +549,7 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     (void)hipGetLastError();
     scratch = nullptr;  // the one-step scatter needs none
   }
-  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, scratch, s);
+  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, scratch, false, s);
   if (scratch) (void)hipFree(scratch);  // emit_index has synchronised the stream
   if (rc != kOk) {
     bwtgpu_index_free(ix);

@@ -695,6 +695,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
             uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
             uint8_t *__restrict__ leaf_ties /* per leaf: 1 if it wrote tie-group heads */,
+            uint32_t *__restrict__ samples /* SA[8 i] at samples[i], or null */,
             Counters *__restrict__ ctr) {
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
@@ -710,6 +711,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
       const uint64_t w = leaf_fetch(tb, src, srckey, start, depth);
       const uint32_t id = word_id(w);
       sa_rows[start] = id;
+      if (samples && !((1 + start) & kDevSampleMask)) samples[(1 + start) >> kDevSampleShift] = id;
       leaf_ties[blockIdx.x] = 0;
       bw[start] = (uint8_t)(w & 3u);
       if (id == 0) ctr->endloc = 1 + start;
@@ -892,6 +894,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
   for (uint32_t j = t; j < size; j += kLeafThreads) {
     const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
+    if (samples && !((1 + start + j) & kDevSampleMask)) samples[(1 + start + j) >> kDevSampleShift] = (uint32_t)o;
     // heads matter to prefix doubling only; a leaf without ties leaves them to k_ghead_identity
     if (ties) ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
     bw[start + j] = (uint8_t)(o >> 44);
@@ -1148,7 +1151,12 @@ int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
 // range's place among all rows is reported in *range.
 int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *range, void *d_ws,
                   size_t ws_bytes, hipStream_t s, SaExtras *extras) {
-  if (extras) *extras = SaExtras{};
+  uint32_t *samples = (extras && !range) ? extras->samples : nullptr;
+  if (extras) {
+    extras->bw = nullptr;
+    extras->endloc = nullptr;
+    extras->samples_done = false;
+  }
   if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
   if (range && (range->dlo >= range->dhi || range->dhi > 256))
     return set_error(kErrArg, "bucket range [%u, %u) is not inside [0, 256)", range->dlo, range->dhi);
@@ -1186,6 +1194,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   // row 0 of the suffix array is the end-of-text suffix (histsortcomp.c:165)
   const uint32_t row0[1] = {n};
   if (!range) BWT_HIP(hipMemcpyAsync(d_sa, row0, 4, hipMemcpyHostToDevice, s));
+  if (samples) BWT_HIP(hipMemcpyAsync(samples, row0, 4, hipMemcpyHostToDevice, s));  // SA[0] = n is row 0's sample
   BWT_HIP(hipMemsetAsync(ghead, 0, 4, s));
 
   uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
@@ -1282,7 +1291,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   g_stats.v[4] = depth;
   if (nleaves_host)
     BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
-               leaves, n, bufA, ghead, bw, leaf_ties, ctr);
+               leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
     BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
@@ -1304,6 +1313,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     // every row came out of a leaf sort: its BWT symbol and the $ row are known
     extras->bw = bw;
     extras->endloc = &ctr->endloc;
+    extras->samples_done = samples != nullptr;
   }
   if (h_ctr.unresolved) {
     // bufB is free from here on: reuse it for the active-row flags
