@@ -95,8 +95,8 @@ def cpu_baseline(args, d_text, n, d_reads, R, m, gpu_sp, gpu_ep):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome-bp", type=int, default=46_000_000)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=50)
