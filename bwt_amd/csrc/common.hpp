@@ -122,6 +122,10 @@ constexpr uint32_t kDevSampleShift = 3;
 constexpr uint32_t kDevSampleMask = (1u << kDevSampleShift) - 1u;
 constexpr uint32_t kFileSampleShift = 5;
 
+// Entries of the list that follows the k-mer table (see index_build_kmer_table):
+// one per suffix shorter than the table's strings, so at most 14.
+constexpr uint32_t kKmerMaxGaps = 16;
+
 }  // namespace bwtgpu
 
 struct bwtgpu_index {
@@ -141,12 +145,15 @@ struct bwtgpu_index {
   uint32_t *d_sa = nullptr;     // n+1 rows
   uint32_t *d_isa = nullptr;    // n+1 positions -> row
   uint32_t *d_text2 = nullptr;  // [0] guard, [1 + w] = bases 16w..16w+15, base k at bits 2k
-  // Optional: the SA interval of every string of kmer_k bases, i.e. the state of
-  // a backward search after its first kmer_k steps, indexed by the string read
-  // as a base-4 number (first base most significant); (0, 0) where the string
-  // does not occur.  A search of a read of at least kmer_k bases starts there.
-  uint2 *d_kmer = nullptr;
+  // Optional: where the SA interval of every string of kmer_k bases starts, i.e.
+  // the state of a backward search after its first kmer_k steps, indexed by the
+  // string read as a base-4 number (first base most significant).  The interval
+  // ends where the next string's starts, less the rows the gap list that follows
+  // the table names (kmer_gaps of them).  A search of a read of at least kmer_k
+  // bases starts there.
+  uint32_t *d_kmer = nullptr;
   uint32_t kmer_k = 0;
+  uint32_t kmer_gaps = 0;
   int device = 0;
 };
 

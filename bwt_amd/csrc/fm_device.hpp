@@ -13,8 +13,9 @@ struct IndexView {
   const uint32_t *sa;     // null unless the index keeps the whole suffix array
   const uint32_t *isa;
   const uint32_t *text2;
-  const uint2 *kmer;      // null unless the index has the k-mer interval table
+  const uint32_t *kmer;   // null unless the index has the k-mer interval table
   uint32_t kmer_k;
+  uint32_t kmer_gaps;
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
@@ -22,7 +23,7 @@ struct IndexView {
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->kmer_k, ix->nsym,  ix->n,      ix->endloc};
+                   ix->d_kmer,   ix->kmer_k, ix->kmer_gaps, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
@@ -42,6 +43,20 @@ __device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
   const uint64_t lo = b->lo, hi = b->hi;
   const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(idx & 63u);
   return base + (uint32_t)__popcll(match);
+}
+
+// The SA interval [sp, return value) of the string numbered x in the k-mer
+// table; empty when the two are equal.
+__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp) {
+  sp = v.kmer[x];
+  uint32_t ep = v.kmer[x + 1];
+  // rows of suffixes shorter than the table's strings that lie between the two
+  const uint2 *gaps = reinterpret_cast<const uint2 *>(v.kmer + (1ull << (2 * v.kmer_k)) + 2);
+  for (uint32_t g = 0; g < v.kmer_gaps; ++g) {
+    const uint2 e = gaps[g];
+    ep -= e.x == x + 1 ? e.y : 0u;
+  }
+  return ep;
 }
 
 // j / 96 and j % 96 for a 32-bit j

@@ -313,38 +313,113 @@ __global__ void k_thin_samples(const uint32_t *__restrict__ dense, uint64_t nsto
 // bases) is one backward-search step (seqindex.c:292-306) from the interval of
 // x.  Strings are numbered with their first base most significant, so
 // neighbouring threads extend neighbouring intervals with the same base and the
-// rank queries of a wave fall on neighbouring blocks.
+// rank queries of a wave fall on neighbouring blocks.  An interval is kept even
+// when it is empty: its start is then the row the string would be inserted at,
+// which is what the step computes (the number of suffixes smaller than c.x).
+// The last level stores the start alone.
+// the four extensions c.x of the string whose interval is iv
+__device__ __forceinline__ void kmer_extend(const IndexView &v, uint2 iv, uint2 o[4]) {
+  const uint32_t a = iv.x - (iv.x > v.endloc), b = iv.y - (iv.y > v.endloc);  // seqindex.c:222-223
+  const IndexBlock *ba = v.blocks + (a >> 6), *bb = v.blocks + (b >> 6);
+  const uint4 oa = *reinterpret_cast<const uint4 *>(ba->occ), ob = *reinterpret_cast<const uint4 *>(bb->occ);
+  const uint64_t la = ba->lo, ha = ba->hi, lb = bb->lo, hb = bb->hi;
+  const uint64_t ma = low_mask(a & 63u), mb = low_mask(b & 63u);
+  const uint32_t occa[4] = {oa.x, oa.y, oa.z, oa.w}, occb[4] = {ob.x, ob.y, ob.z, ob.w};
+#pragma unroll
+  for (uint32_t c = 0; c < 4; ++c) {
+    const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
+    o[c] = make_uint2(occa[c] + (uint32_t)__popcll((la ^ nlo) & (ha ^ nhi) & ma),
+                      occb[c] + (uint32_t)__popcll((lb ^ nlo) & (hb ^ nhi) & mb));
+  }
+}
+
+template <bool LAST>
 __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
-                             uint32_t j) {
+                             uint32_t *__restrict__ dst_start, uint32_t j) {
   // one thread per string x of j bases: the two blocks its interval ends fall
   // in serve all four extensions c.x
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t parents = 1ull << (2 * j);
   if (p >= parents) return;
   const uint2 iv = src[p];
-  uint2 o[4] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-  if (iv.y > iv.x) {
-    const uint32_t a = iv.x - (iv.x > v.endloc), b = iv.y - (iv.y > v.endloc);  // seqindex.c:222-223
-    const IndexBlock *ba = v.blocks + (a >> 6), *bb = v.blocks + (b >> 6);
-    const uint4 oa = *reinterpret_cast<const uint4 *>(ba->occ), ob = *reinterpret_cast<const uint4 *>(bb->occ);
-    const uint64_t la = ba->lo, ha = ba->hi, lb = bb->lo, hb = bb->hi;
-    const uint64_t ma = low_mask(a & 63u), mb = low_mask(b & 63u);
-    const uint32_t occa[4] = {oa.x, oa.y, oa.z, oa.w}, occb[4] = {ob.x, ob.y, ob.z, ob.w};
+  if (LAST) {
+    const uint32_t a = iv.x - (iv.x > v.endloc);
+    const IndexBlock *ba = v.blocks + (a >> 6);
+    const uint4 oa = *reinterpret_cast<const uint4 *>(ba->occ);
+    const uint64_t la = ba->lo, ha = ba->hi;
+    const uint64_t ma = low_mask(a & 63u);
+    const uint32_t occa[4] = {oa.x, oa.y, oa.z, oa.w};
 #pragma unroll
     for (uint32_t c = 0; c < 4; ++c) {
       const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
-      const uint32_t sp = occa[c] + (uint32_t)__popcll((la ^ nlo) & (ha ^ nhi) & ma);
-      const uint32_t ep = occb[c] + (uint32_t)__popcll((lb ^ nlo) & (hb ^ nhi) & mb);
-      if (ep > sp) o[c] = make_uint2(sp, ep);
+      dst_start[(uint64_t)c * parents + p] = occa[c] + (uint32_t)__popcll((la ^ nlo) & (ha ^ nhi) & ma);
     }
+    return;
   }
+  uint2 o[4];
+  kmer_extend(v, iv, o);
 #pragma unroll
   for (uint32_t c = 0; c < 4; ++c) dst[(uint64_t)c * parents + p] = o[c];
 }
 
+struct KmerFirst {
+  uint32_t c[5];
+};
+constexpr uint32_t kKmerHeadLevels = 5;  // 4^4 strings is what one workgroup extends in one go
+
+// Workgroup 0: levels 1..top of the table (top <= kKmerHeadLevels, top < K)
+// through LDS, level `top` written to dst.  Workgroup 1: what follows the
+// table's 4^K starts -- the closing start n + 1, a word of padding, and one
+// (string, 1) pair per suffix shorter than K bases, the string being that
+// suffix padded with A to K bases; the last K - 1 bases of the text are read
+// off the index by walking LF from the row of the empty suffix
+// (seqindex.c:214-219).  Unused pairs name no string.
+__global__ void __launch_bounds__(256) k_kmer_head(IndexView v, KmerFirst C, uint32_t top, uint32_t K,
+                                                    uint2 *__restrict__ dst, uint32_t *__restrict__ tab) {
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x == 1) {
+    if (t) return;
+    uint32_t *trailer = tab + (1ull << (2 * K));
+    trailer[0] = v.n + 1;
+    trailer[1] = 0;
+    uint2 *gaps = reinterpret_cast<uint2 *>(trailer + 2);
+    uint32_t idx = 0, val = 0, L = 1;
+    for (; L < K && idx != v.endloc; ++L) {
+      const uint32_t jj = idx - (idx > v.endloc);
+      const IndexBlock *b = v.blocks + (jj >> 6);
+      const uint32_t c = (uint32_t)((b->lo >> (jj & 63u)) & 1ull) | ((uint32_t)((b->hi >> (jj & 63u)) & 1ull) << 1);
+      val |= c << (2 * (L - 1));  // the suffix of L bases, first base most significant
+      gaps[L - 1] = make_uint2(val << (2 * (K - L)), 1u);
+      idx = lf_step(v, idx);
+    }
+    for (; L <= kKmerMaxGaps; ++L) gaps[L - 1] = make_uint2(0xFFFFFFFFu, 0u);
+    return;
+  }
+  __shared__ uint2 lv[2][256];
+  if (t < 4) {
+    const uint2 e = make_uint2(t == 0 ? C.c[0] : t == 1 ? C.c[1] : t == 2 ? C.c[2] : C.c[3],
+                               t == 0 ? C.c[1] : t == 1 ? C.c[2] : t == 2 ? C.c[3] : C.c[4]);
+    if (top == 1) dst[t] = e;
+    else lv[1][t] = e;
+  }
+  for (uint32_t j = 1; j < top; ++j) {
+    __syncthreads();
+    const uint32_t parents = 1u << (2 * j);
+    if (t < parents) {
+      uint2 o[4];
+      kmer_extend(v, lv[j & 1u][t], o);
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) {
+        if (j + 1 == top) dst[c * parents + t] = o[c];
+        else lv[(j + 1) & 1u][c * parents + t] = o[c];
+      }
+    }
+  }
+}
+
 // Table size: the smallest k with 4^k >= n, so that the interval of a string
 // of k bases is a single row more often than not, at most 4^15 entries
-// (8 GiB); BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT
+// (4 GiB); BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT
 // means none.
 static uint32_t kmer_table_k(uint32_t n) {
   if (getenv("BWT_MI355X_COMPACT")) return 0;
@@ -357,40 +432,60 @@ static uint32_t kmer_table_k(uint32_t n) {
   return k < 6 ? 0u : k;
 }
 
+// Layout of the table buffer: 4^K + 1 interval starts (the last is n + 1), one
+// word of padding, then kKmerMaxGaps (string, rows) pairs.
+//
+// start[x + 1] is the end of the interval of x unless rows of suffixes shorter
+// than K bases lie between the two: a suffix s of L < K bases sorts after every
+// string smaller than s and before every string s is a prefix of, so its row
+// sits right before the interval of s.AA..A and nowhere else.  There are at
+// most K - 1 such suffixes; the pairs list the strings s.AA..A, and a lookup
+// subtracts the rows of the pairs that name the next string.
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   const uint32_t K = kmer_table_k(ix->n);
   if (K == 0) return kOk;
+  static_assert(kKmerMaxGaps >= 14, "one pair per suffix shorter than the longest table string");
   const uint64_t entries = 1ull << (2 * K);
-  uint2 *tab = nullptr, *tmp = nullptr;
-  if (pool_alloc(&tab, entries * sizeof(uint2)) != hipSuccess ||
-      pool_alloc(&tmp, (entries / 4) * sizeof(uint2)) != hipSuccess) {
+  const size_t tab_bytes = (entries + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2);
+  uint32_t *tab = nullptr;
+  uint2 *tmp_a = nullptr, *tmp_b = nullptr;
+  if (pool_alloc(&tab, tab_bytes) != hipSuccess ||
+      pool_alloc(&tmp_a, (entries / 4) * sizeof(uint2)) != hipSuccess ||
+      pool_alloc(&tmp_b, (entries / 16) * sizeof(uint2)) != hipSuccess) {
     (void)hipGetLastError();  // short of memory: searches start from the first base instead
     pool_free(tab);
+    pool_free(tmp_a);
     return kOk;
   }
-  // level j lives in tab when K - j is even, in tmp otherwise, so level K ends in tab
-  auto buf = [&](uint32_t j) { return ((K - j) & 1u) ? tmp : tab; };
-  uint2 first[4];
-  for (uint32_t c = 0; c < 4; ++c)
-    first[c] = ix->C[c + 1] > ix->C[c] ? make_uint2(ix->C[c], ix->C[c + 1]) : make_uint2(0u, 0u);
-  hipError_t e = hipMemcpyAsync(buf(1), first, sizeof first, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);  // first[] leaves the stack
+  // level j < K lives in tmp_a when K - 1 - j is even, in tmp_b otherwise
+  auto buf = [&](uint32_t j) { return ((K - 1 - j) & 1u) ? tmp_b : tmp_a; };
   const IndexView v = view_of(ix);
-  for (uint32_t j = 1; j < K && e == hipSuccess; ++j) {
+  KmerFirst first;
+  for (uint32_t c = 0; c < 5; ++c) first.c[c] = ix->C[c];
+  const uint32_t top = K - 1 < kKmerHeadLevels ? K - 1 : kKmerHeadLevels;
+  BWT_LAUNCH("kmer_head", k_kmer_head, dim3(2), dim3(256), 0, s, v, first, top, K, buf(top), tab);
+  hipError_t e = hipGetLastError();
+  for (uint32_t j = top; j < K && e == hipSuccess; ++j) {
     const uint64_t parents = 1ull << (2 * j);
-    BWT_LAUNCH("kmer_level", k_kmer_level, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v, buf(j),
-               buf(j + 1), j);
+    if (j + 1 < K)
+      BWT_LAUNCH("kmer_level", k_kmer_level<false>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
+                 buf(j), buf(j + 1), (uint32_t *)nullptr, j);
+    else
+      BWT_LAUNCH("kmer_level", k_kmer_level<true>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
+                 buf(j), (uint2 *)nullptr, tab, j);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) (void)hipDeviceSynchronize();
-  pool_free(tmp);
+  pool_free(tmp_a);
+  pool_free(tmp_b);
   if (e != hipSuccess) {
     pool_free(tab);
     return set_error(kErrHip, "k-mer table build: %s", hipGetErrorString(e));
   }
   ix->d_kmer = tab;
   ix->kmer_k = K;
+  ix->kmer_gaps = K - 1;
   return kOk;
 }
 
@@ -535,7 +630,7 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
          (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
-         (ix->d_kmer ? sizeof(uint2) << (2 * ix->kmer_k) : 0);
+         (ix->d_kmer ? ((1ull << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2) : 0);
 }
 
 int bwtgpu_index_compact(bwtgpu_index *ix) {
@@ -551,6 +646,7 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
   ix->kmer_k = 0;
+  ix->kmer_gaps = 0;
   return kOk;
 }
 

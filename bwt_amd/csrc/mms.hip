@@ -85,10 +85,11 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
       x = (x << 2) | (raw & 3u);
     }
     if (plain) {
-      const uint2 e = v.kmer[x];
-      if (e.y > e.x) {
-        start = e.x;
-        end = e.y;
+      uint32_t e_sp;
+      const uint32_t e_ep = kmer_interval(v, x, e_sp);
+      if (e_ep > e_sp) {
+        start = e_sp;
+        end = e_ep;
         i = len - K - 1;
       } else if (K <= at_least && skips == 0) {
         // fewer than K bases match and none was skipped: below the caller's bar

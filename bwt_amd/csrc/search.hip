@@ -150,11 +150,12 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     uint32_t x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (a & 15u)));  // base a in the low bits
     x = __brev(x);
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);  // base a in the top bits
-    const uint2 e = v.kmer[x >> (32 - 2 * K)];
+    uint32_t e_sp;
+    const uint32_t e_ep = kmer_interval(v, x >> (32 - 2 * K), e_sp);
     if (COUNT) ++n_kmr;
-    if (e.y > e.x) {
-      sp = e.x;
-      ep = e.y;
+    if (e_ep > e_sp) {
+      sp = e_sp;
+      ep = e_ep;
       word = w0;
       i = (int)a - 1;
     }

@@ -270,6 +270,35 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     assert loads["kmer_entries_8B"] == (3000 if k >= 2 else 0)
 
 
+@pytest.mark.parametrize("tail", ["CAAA", "TTTT", "GATTACA", "AAAAAAAA", "ACGT"])
+@pytest.mark.parametrize("k", [2, 3, 5, 6])
+def test_kmer_table_around_the_short_suffixes(oracle, gpu, k, tail, monkeypatch):
+    """The table keeps interval starts only; an interval ends where the next one
+    starts except where rows of suffixes shorter than k lie between.  Every
+    string of k and of k + 1 bases is searched on texts whose last bases make
+    those rows fall before, between and after occupied intervals."""
+    rng = np.random.default_rng(len(tail) * 16 + k)
+    for n in (len(tail), len(tail) + 1, 40, 3001):
+        bases = rng.integers(0, 4, n).astype(np.uint8)
+        bases[n - len(tail):] = ["ACGT".index(ch) for ch in tail]
+        text = synth.pack(bases)
+        fo = oracle.make_fmi(text, n)
+        monkeypatch.setenv("BWT_MI355X_KMER", str(k))
+        full = gpu.build_index(text, n)
+        lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+        monkeypatch.delenv("BWT_MI355X_KMER")
+        for m in (k, k + 1):
+            R = 4 ** m
+            x = np.arange(R, dtype=np.uint32)
+            reads = np.stack([(x >> (2 * (m - 1 - j))) & 3 for j in range(m)], axis=1).astype(np.uint8)
+            sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+            d = torch.from_numpy(reads.reshape(-1)).cuda()
+            for name, ix in (("full", full), ("lean", lean)):
+                sp, ep = (gpu.to_numpy_u32(t) for t in ix.search(d, m, R))
+                np.testing.assert_array_equal(sp, sp_o, err_msg=f"{name} n={n} m={m}")
+                np.testing.assert_array_equal(ep, ep_o, err_msg=f"{name} n={n} m={m}")
+
+
 @pytest.mark.parametrize("levels", ["1", "2"])
 @pytest.mark.parametrize("n", [5000, 100003, 3000000])
 def test_two_step_inverse_suffix_array(oracle, gpu, n, levels, monkeypatch):
