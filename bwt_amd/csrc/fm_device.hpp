@@ -48,11 +48,17 @@ __device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
 // The SA interval [sp, return value) of the string numbered x in the k-mer
 // table; empty when the two are equal.
 __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp) {
-  sp = v.kmer[x];
-  uint32_t ep = v.kmer[x + 1];
-  // rows of suffixes shorter than the table's strings that lie between the two
+  // one 8-byte load at a 4-byte aligned address: both starts in one request
+  uint64_t both;
+  __builtin_memcpy(&both, v.kmer + x, sizeof both);
+  sp = (uint32_t)both;
+  uint32_t ep = (uint32_t)(both >> 32);
+  // rows of suffixes shorter than the table's strings that lie between the two;
+  // every pair is read (unused ones name no string): the loads are uniform and
+  // issue together
   const uint2 *gaps = reinterpret_cast<const uint2 *>(v.kmer + (1ull << (2 * v.kmer_k)) + 2);
-  for (uint32_t g = 0; g < v.kmer_gaps; ++g) {
+#pragma unroll
+  for (uint32_t g = 0; g < kKmerMaxGaps; ++g) {
     const uint2 e = gaps[g];
     ep -= e.x == x + 1 ? e.y : 0u;
   }
