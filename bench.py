@@ -333,6 +333,9 @@ def main():
             "traffic": measured_traffic(f"{n}bp_{R}x{m}"),
             # the kernel is bound by how many cache lines per second leave L2, not by bytes
             "l2_miss_lines_per_s": (measured_traffic(f"{n}bp_{R}x{m}_l2_misses") or 0) / (k_ms * 1e-3) if k_ms else None,
+            # what plain random 4-byte gathers over 24 GiB reach on this GPU (tools_probe/gather_probe.hip,
+            # profiles/r1_gather_probe.txt): the ceiling for loads with no locality
+            "random_gather_lines_per_s": 46e9,
             "bytes_per_read": bpr,
             "loads": loads,
             "counting_pass_matches": counted_ok,

@@ -132,7 +132,8 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
  * produces, the whole suffix array, its inverse and the text (8.25 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
  * every index also holds a table of the SA intervals of all strings of k bases
- * (k = ceil(log4 n), at most 15; BWT_MI355X_KMER=<k> overrides), where
+ * (k = ceil(log4 n), at most 15, 4 bytes per string; BWT_MI355X_KMER=<k>
+ * overrides), where
  * searches of longer reads start.  Results are the same with or without them.
  * This call frees all four and leaves the rank blocks and the sampled suffix
  * array.  Setting BWT_MI355X_COMPACT in the environment makes every build and
@@ -157,7 +158,7 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                   uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
 /* bwtgpu_search, and the number of loads the batch made: loads[0] 16-byte rank
  * blocks, loads[1] 8-byte text windows, loads[2] 4-byte SA/ISA entries,
- * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table entries.
+ * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table lookups.
  * For measurement (bytes a search
  * needs); slower than bwtgpu_search and synchronises the stream.  Workspace:
  * bwtgpu_search_workspace_bytes(R, m) + 256 bytes.  No counterpart in the
