@@ -341,7 +341,7 @@ def main():
             "counting_pass_matches": counted_ok,
             "kernel_ms": k_ms,
             "what": "bytes the kernel loads and stores, counted per batch by its counting build "
-                    "(16 B rank blocks, 8 B text windows, 4 B SA/ISA entries, 8 B table entry, the read itself, "
+                    "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries, 8 B table entry, the read itself, "
                     "12 B out)",
             "reads_packed_in_kernel": fused,
         },

@@ -122,6 +122,26 @@ constexpr uint32_t kDevSampleShift = 3;
 constexpr uint32_t kDevSampleMask = (1u << kDevSampleShift) - 1u;
 constexpr uint32_t kFileSampleShift = 5;
 
+// The inverse suffix array lives in 64-byte records of twelve positions: the
+// twelve rows, then the 64 bases of text that start at the record's first
+// position (base k at bits 2k of word k / 16).  A search that has narrowed to
+// one row compares the rest of its read with the text and then needs the row
+// of the position the read starts at: one record -- one cache line -- holds
+// both for reads that start in it and are up to 53 bases long; every further
+// 48 bases cost one more record (48 = 4 records, so the offset stays).  Four
+// guard records of zeros come first (a read may overhang the start of the
+// text), i.e. position p is slot p % 12 of record p / 12 + 4.
+struct __attribute__((aligned(64))) PosRecord {
+  uint32_t row[12];
+  uint32_t text[4];
+};
+static_assert(sizeof(PosRecord) == 64, "one position record = one cache line");
+constexpr uint32_t kPosPerRecord = 12;
+constexpr uint32_t kPosGuardRecords = 4;
+// largest text whose position + guard still fits 32 bits
+constexpr uint32_t kPosRecordMaxN = 0xFFFFFF00u;
+inline uint64_t pos_record_count(uint32_t n) { return (uint64_t)n / kPosPerRecord + kPosGuardRecords + 2; }
+
 // Entries of the list that follows the k-mer table (see index_build_kmer_table):
 // one per suffix shorter than the table's strings, so at most 14.
 constexpr uint32_t kKmerMaxGaps = 16;
@@ -138,12 +158,12 @@ struct bwtgpu_index {
   bwtgpu::SymBlock *d_sym = nullptr;  // [4][nsym]
   uint32_t *d_idxs = nullptr;  // 1 + n/8 sampled SA rows: SA[8 i]
   // Optional, kept when the index was built from the text and HBM allows
-  // (8.25 more bytes per base): the whole suffix array, its inverse, and the
+  // (9.6 more bytes per base): the whole suffix array, its inverse, and the
   // text as 16-base little-endian words behind one guard word.  With them a
   // search finishes by comparing the read with the text once its interval is a
   // single row, and locate is one lookup.
   uint32_t *d_sa = nullptr;     // n+1 rows
-  uint32_t *d_isa = nullptr;    // n+1 positions -> row
+  uint32_t *d_isa = nullptr;    // position -> row, as pos_record_count(n) PosRecords (with their text)
   uint32_t *d_text2 = nullptr;  // [0] guard, [1 + w] = bases 16w..16w+15, base k at bits 2k
   // Optional: where the SA interval of every string of kmer_k bases starts, i.e.
   // the state of a backward search after its first kmer_k steps, indexed by the

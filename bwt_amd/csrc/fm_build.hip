@@ -103,10 +103,9 @@ k_check_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa
   if (lane == 0 && (blocks[b].lo != lo || blocks[b].hi != hi)) *mismatch = 1u;
 }
 
-__global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows,
-                             uint32_t *__restrict__ isa) {
+__global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t *__restrict__ isa) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < rows) isa[sa[j]] = (uint32_t)j;
+  if (j < rows) isa[isa_slot(sa[j])] = (uint32_t)j;
 }
 
 // Inverse of a suffix array, in two steps so that the 4-byte scatter stays
@@ -215,14 +214,38 @@ __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
   const uint64_t j = chunk * blockDim.x + threadIdx.x;
   if (j >= rows) return;
   const uint64_t pr = pairs[j];
-  isa[(uint32_t)pr] = (uint32_t)(pr >> 32);
+  isa[isa_slot((uint32_t)pr)] = (uint32_t)(pr >> 32);
 }
 
-// ISA of the n+1 rows at d_sa.  scratch (may be null): 8 (n+1) + 2048 bytes
-// that nothing else is using.
-static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_isa, void *scratch,
-                                hipStream_t s) {
+// The text part of every position record: the 64 bases from the record's first
+// position on, zeros before the text and from base n on.  (Written apart from
+// the rows: the threads that fill in the rows hold them in no order, and having
+// them fetch the text as well cost more than this pass.)
+__global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, uint64_t nrec,
+                              uint32_t *__restrict__ recs) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nrec) return;
+  const int64_t first = ((int64_t)b - kPosGuardRecords) * kPosPerRecord;
+  uint32_t w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t at = first + 16 * k;
+    w[k] = (at <= -16 || at >= (int64_t)n) ? 0u : text16(text2, at);
+  }
+  // whole records (rows zeroed, to be filled in next): whole lines to memory
+  uint4 *rec = reinterpret_cast<uint4 *>(recs) + b * 4;
+  rec[0] = rec[1] = rec[2] = make_uint4(0u, 0u, 0u, 0u);
+  rec[3] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// The position records at d_isa: the inverse of the n+1 rows at d_sa and the
+// text from d_text2.  scratch (may be null): 8 (n+1) + 2048 bytes that nothing
+// else is using.
+static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t *d_text2, uint32_t *d_isa,
+                                void *scratch, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1;
+  BWT_LAUNCH("record_text", k_record_text, dim3((unsigned)div_up(pos_record_count(n), 256)), dim3(256), 0, s,
+             d_text2, n, pos_record_count(n), d_isa);
   // small arrays sit in L2 whatever the order of the stores
   const char *env = getenv("BWT_MI355X_ISA_TWO_STEP");  // for tests on small texts: 1 = one level, 2 = two
   const bool force = env != nullptr, force2 = env && env[0] == '2';
@@ -241,7 +264,7 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
   uint32_t window_shift = shift;
   uint64_t *pairs2 = nullptr;
   unsigned long long *d_cur2 = nullptr;
-  if (((4ull << shift) > (2ull << 20) || force2) && shift >= 13) {  // tiles of 2^13 pairs must not straddle bins
+  if (((6ull << shift) > (2ull << 20) || force2) && shift >= 13) {  // tiles of 2^13 pairs must not straddle bins
     // windows beyond an L2: split each bin once more, if there is room for a second pair buffer
     if (pool_alloc(&pairs2, rows * 8) == hipSuccess && pool_alloc(&d_cur2, 65536 * 8) == hipSuccess) {
       const uint32_t shift2 = shift - 8;
@@ -254,7 +277,7 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, uint32_t *d_is
       (void)hipGetLastError();
     }
   }
-  const int xcd_local = (4ull << window_shift) <= (2ull << 20);  // a window of ISA entries within half an L2
+  const int xcd_local = (6ull << window_shift) <= (2ull << 20);  // a window of records within half an L2
   BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, filled,
              rows, d_isa, xcd_local);
   hipError_t e = hipGetLastError();
@@ -356,10 +379,10 @@ static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
 // Allocates the arrays an index keeps beside what make_fmi produces, unless
 // asked not to or HBM is short.
 static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
-  if (getenv("BWT_MI355X_COMPACT")) return;
+  if (getenv("BWT_MI355X_COMPACT") || n > kPosRecordMaxN) return;
   const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   hipError_t ea = pool_alloc(&ix->d_sa, rows_all * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, rows_all * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord));
   if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
   if (ea != hipSuccess) {
     (void)hipGetLastError();
@@ -393,9 +416,9 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
   if (!have_samples)  // else the leaf sort dropped them as it wrote the rows
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
   if (ix->d_sa) {
-    BWT_TRY(inverse_suffix_array(d_sa, n, ix->d_isa, isa_scratch, s));
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
+    BWT_TRY(inverse_suffix_array(d_sa, n, ix->d_text2, ix->d_isa, isa_scratch, s));
   }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
@@ -565,8 +588,9 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   BWT_HIP(hipSetDevice(ix->device));
   const uint32_t n = ix->n;
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  if (n > kPosRecordMaxN) return set_error(kErrArg, "text of %u bases is too long to keep beside its index", n);
   hipError_t ea = pool_alloc(&ix->d_sa, rows * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, rows * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord));
   if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
   auto drop = [&]() {
     (void)hipDeviceSynchronize();
@@ -604,10 +628,10 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
       rc = set_error(kErrArg, "this text is not the one the index was built from");
   }
   if (rc == kOk) {
-    rc = inverse_suffix_array(ix->d_sa, n, ix->d_isa, sa_workspace_free_region(n, g_cache.ws), s);
+    BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
+               t2words, ix->d_text2);
+    rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, ix->d_isa, sa_workspace_free_region(n, g_cache.ws), s);
     if (rc == kOk) {
-      BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
-                 t2words, ix->d_text2);
       if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
         rc = set_error(kErrHip, "attaching the text failed");
     }

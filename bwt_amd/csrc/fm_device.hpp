@@ -11,7 +11,7 @@ struct IndexView {
   const SymBlock *sym;
   const uint32_t *idxs;
   const uint32_t *sa;     // null unless the index keeps the whole suffix array
-  const uint32_t *isa;
+  const uint32_t *isa;    // PosRecords, 16 words each
   const uint32_t *text2;
   const uint32_t *kmer;   // null unless the index has the k-mer interval table
   uint32_t kmer_k;
@@ -64,6 +64,30 @@ __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x
   }
   return ep;
 }
+
+// 16 bases of text starting at position o (o >= -15), base k of the result at
+// bits 2k; text2[0] is a guard word so that o may reach 15 below zero.
+__device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, int64_t o) {
+  const uint64_t q = (uint64_t)(o + 16);
+  const uint64_t both = ((uint64_t)text2[(q >> 4) + 1] << 32) | text2[q >> 4];
+  return (uint32_t)(both >> (2u * (uint32_t)(q & 15u)));
+}
+
+// p / 12 and p % 12 for a 32-bit p
+__device__ __forceinline__ uint32_t div12(uint32_t p, uint32_t &rem) {
+  const uint32_t q = __umulhi(p, 0xAAAAAAABu) >> 3;
+  rem = p - q * kPosPerRecord;
+  return q;
+}
+
+// word index of position p's row in the array of PosRecords
+__device__ __forceinline__ uint64_t isa_slot(uint32_t p) {
+  uint32_t o;
+  const uint32_t b = div12(p, o);
+  return ((uint64_t)b + kPosGuardRecords) * 16u + o;
+}
+
+__device__ __forceinline__ uint32_t isa_at(const IndexView &v, uint32_t p) { return v.isa[isa_slot(p)]; }
 
 // j / 96 and j % 96 for a 32-bit j
 __device__ __forceinline__ uint32_t div96(uint32_t j, uint32_t &rem) {

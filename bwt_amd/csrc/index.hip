@@ -629,7 +629,7 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
-         (ix->d_sa ? 2 * ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
+         (ix->d_sa ? ((size_t)ix->n + 1) * 4 + pos_record_count(ix->n) * sizeof(PosRecord) + ((size_t)ix->n / 16 + 4) * 4 : 0) +
          (ix->d_kmer ? ((1ull << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2) : 0);
 }
 

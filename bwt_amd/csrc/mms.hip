@@ -112,7 +112,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
         if (raw != 5 && (raw & 3u) != text_base2(v, pos - 1 - k)) break;
         ++k;
       }
-      const uint32_t row = k ? v.isa[pos - k] : start;
+      const uint32_t row = k ? isa_at(v, pos - k) : start;
       *sp_out = row;
       *ep_out = row + 1;
       return len - 1 - i + (int)k + skips;

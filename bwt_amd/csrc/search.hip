@@ -69,14 +69,6 @@ struct CTable {
   uint32_t c[5];
 };
 
-// 16 bases of text starting at position o (o >= -15), base k of the result at
-// bits 2k; text2[0] is a guard word so that o may reach 15 below zero.
-__device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, int64_t o) {
-  const uint64_t q = (uint64_t)(o + 16);
-  const uint64_t both = ((uint64_t)text2[(q >> 4) + 1] << 32) | text2[q >> 4];
-  return (uint32_t)(both >> (2u * (uint32_t)(q & 15u)));
-}
-
 // Backward search (loc_search, seqindex.c:280-309), one read per lane.
 // d_locrow (optional) receives the row locate() would hand to unc_sa
 // (seqindex.c:265-276): sp unless the interval emptied before the last step.
@@ -90,7 +82,7 @@ __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, i
 // handful of reads instead of two rank queries per remaining base.
 //
 // COUNT adds up what the batch loaded (see bwtgpu_search_profile): counters[0]
-// 16-byte rank blocks, [1] 8-byte text windows, [2] 4-byte SA/ISA entries,
+// 16-byte rank blocks, [1] 16-byte text windows, [2] 4-byte SA/ISA entries,
 // [3] 4-byte pattern words, [4] 8-byte k-mer table entries.
 //
 // FUSED: the reads are packed inside the kernel instead of by k_pack_reads: a
@@ -198,31 +190,47 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     const uint32_t pos = v.sa[sp];
     if (COUNT) n_ent += 2;  // this and the one ISA entry read below
     const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
-    // the highest read base j in [jmin, rem) that differs from text[pos - rem + j]
+    // the highest read base j in [jmin, rem) that differs from text[pos - rem + j];
+    // the record of position pos - rem + 48 g holds the text for read words 3g..3g+2
     int jbad = -1;
-    for (int w = (int)((rem - 1) >> 4); w >= 0 && jbad < 0; --w) {
-      const uint32_t lo = jmin > 16u * w ? jmin - 16u * w : 0u;
-      if (lo >= 16) break;
-      const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
-      const uint32_t rw = word_at((uint32_t)(w));
-      const uint32_t tw = text16(v.text2, (int64_t)pos - rem + 16 * w);
-      if (COUNT) {
-        ++n_txt;
-        ++n_pat;
+    uint32_t row_all = 0;  // ISA[pos - rem]: in the record read last
+    bool before_text = false;
+    for (int g = (int)((rem - 1) / 48u); g >= 0 && jbad < 0 && !before_text; --g) {
+      if (48u * g + 48u <= jmin) break;
+      uint32_t o;
+      const uint32_t b = div12((pos + 48u) - (rem - 48u * g), o);  // guard records included
+      const uint4 tx = reinterpret_cast<const uint4 *>(v.isa)[(uint64_t)b * 4u + 3u];
+      if (g == 0 && jmin == 0) row_all = v.isa[(uint64_t)b * 16u + o];
+      if (COUNT) ++n_txt;
+      for (int wl = 2; wl >= 0 && jbad < 0; --wl) {
+        const uint32_t w = 3u * g + wl;
+        if (16u * w >= rem) continue;
+        if (16u * w + 16u <= jmin) {
+          before_text = true;
+          break;
+        }
+        const uint32_t lo = jmin > 16u * w ? jmin - 16u * w : 0u;
+        const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
+        const uint32_t rw = word_at(w);
+        if (COUNT) ++n_pat;
+        const uint32_t at = o + 16u * wl, wi = at >> 4;  // 16 bases from base `at` of the record's 64
+        const uint32_t t_lo = wi == 0 ? tx.x : wi == 1 ? tx.y : tx.z;
+        const uint32_t t_hi = wi == 0 ? tx.y : wi == 1 ? tx.z : tx.w;
+        const uint32_t tw = (uint32_t)((((uint64_t)t_hi << 32) | t_lo) >> (2u * (at & 15u)));
+        uint32_t d = rw ^ tw;
+        d = (d | (d >> 1)) & 0x55555555u;
+        const uint32_t keep = (hi == 16 ? ~0u : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
+        d &= keep;
+        if (d) jbad = 16 * (int)w + (31 - __clz((int)d)) / 2;
       }
-      uint32_t d = rw ^ tw;
-      d = (d | (d >> 1)) & 0x55555555u;
-      const uint32_t keep = (hi == 16 ? ~0u : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
-      d &= keep;
-      if (d) jbad = 16 * w + (31 - __clz((int)d)) / 2;
     }
     if (jbad < 0 && jmin > 0) jbad = (int)jmin - 1;  // ran off the start of the text
     if (jbad < 0) {
-      sp = v.isa[pos - rem];
+      sp = row_all;
       ep = sp + 1;
     } else {
       const uint32_t k = rem - 1 - (uint32_t)jbad;  // bases that did match
-      const uint32_t row = k ? v.isa[pos - k] : sp;
+      const uint32_t row = k ? isa_at(v, pos - k) : sp;
       c = (word_at((uint32_t)(jbad >> 4)) >> (2 * (jbad & 15))) & 3u;
       const uint32_t js = row - (row > v.endloc), je = row + 1 - (row + 1 > v.endloc);
       uint32_t rs, re;

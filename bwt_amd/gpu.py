@@ -144,9 +144,9 @@ class GpuIndex:
         check(lib.bwtgpu_search_profile(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(ws),
                                         ws.numel(), loads, _stream()))
         blk, txt, ent, pat, kmr = (int(x) for x in loads)
-        return {"rank_blocks_16B": blk, "text_windows_8B": txt, "sa_isa_entries_4B": ent,
+        return {"rank_blocks_16B": blk, "text_windows_16B": txt, "sa_isa_entries_4B": ent,
                 "pattern_words_4B": pat, "kmer_entries_8B": kmr,
-                "bytes": 16 * blk + 8 * txt + 4 * ent + 4 * pat + 8 * kmr}, sp, ep
+                "bytes": 16 * blk + 16 * txt + 4 * ent + 4 * pat + 8 * kmr}, sp, ep
 
     def attach_text(self, text):
         """Give an index loaded from its stored parts the text it was built from

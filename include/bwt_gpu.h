@@ -129,7 +129,7 @@ int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows);
 int bwtgpu_index_rank_rows(const bwtgpu_index *ix, uint32_t blocksize, uint32_t *h_rows);
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
 /* An index built on the device keeps, beside what make_fmi (seqindex.c:161-189)
- * produces, the whole suffix array, its inverse and the text (8.25 bytes per
+ * produces, the whole suffix array, its inverse and the text (9.6 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
  * every index also holds a table of the SA intervals of all strings of k bases
  * (k = ceil(log4 n), at most 15, 4 bytes per string; BWT_MI355X_KMER=<k>
@@ -157,7 +157,7 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                   uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
                   uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
 /* bwtgpu_search, and the number of loads the batch made: loads[0] 16-byte rank
- * blocks, loads[1] 8-byte text windows, loads[2] 4-byte SA/ISA entries,
+ * blocks, loads[1] 16-byte text windows, loads[2] 4-byte SA/ISA entries,
  * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table lookups.
  * For measurement (bytes a search
  * needs); slower than bwtgpu_search and synchronises the stream.  Workspace:

@@ -233,8 +233,8 @@ def test_compact_drops_the_kept_arrays_and_counting_search_agrees(oracle, gpu):
     loads_lean, sp, ep = ix.search_loads(d, m, R)
     np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
-    assert loads_lean["text_windows_8B"] == 0 and loads_lean["sa_isa_entries_4B"] == 0
-    assert loads_full["text_windows_8B"] > 0
+    assert loads_lean["text_windows_16B"] == 0 and loads_lean["sa_isa_entries_4B"] == 0
+    assert loads_full["text_windows_16B"] > 0
     assert loads_full["rank_blocks_16B"] < loads_lean["rank_blocks_16B"] <= 2 * (m - 1) * R
     rows = torch.arange(0, n + 1, 7, dtype=torch.int64, device="cuda").to(torch.int32)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n)[::7])
@@ -339,7 +339,7 @@ def test_attach_text_to_a_loaded_index(oracle, gpu):
     loads, sp, ep = ix.search_loads(d, m, R)
     np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
-    assert loads["text_windows_8B"] > 0
+    assert loads["text_windows_16B"] > 0
     rows = torch.arange(0, n + 1, 5, dtype=torch.int64, device="cuda").to(torch.int32)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n)[::5])
     # device-resident text
