@@ -220,7 +220,8 @@ __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
 // The text part of every position record: the 64 bases from the record's first
 // position on, zeros before the text and from base n on.  (Written apart from
 // the rows: the threads that fill in the rows hold them in no order, and having
-// them fetch the text as well cost more than this pass.)
+// them fetch the text as well cost more than this pass; and after them: run
+// first, its lines were still in the caches when the pairs were being dealt.)
 __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, uint64_t nrec,
                               uint32_t *__restrict__ recs) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,10 +233,7 @@ __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, ui
     const int64_t at = first + 16 * k;
     w[k] = (at <= -16 || at >= (int64_t)n) ? 0u : text16(text2, at);
   }
-  // whole records (rows zeroed, to be filled in next): whole lines to memory
-  uint4 *rec = reinterpret_cast<uint4 *>(recs) + b * 4;
-  rec[0] = rec[1] = rec[2] = make_uint4(0u, 0u, 0u, 0u);
-  rec[3] = make_uint4(w[0], w[1], w[2], w[3]);
+  reinterpret_cast<uint4 *>(recs)[b * 4 + 3] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // The position records at d_isa: the inverse of the n+1 rows at d_sa and the
@@ -244,13 +242,16 @@ __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, ui
 static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t *d_text2, uint32_t *d_isa,
                                 void *scratch, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1;
-  BWT_LAUNCH("record_text", k_record_text, dim3((unsigned)div_up(pos_record_count(n), 256)), dim3(256), 0, s,
-             d_text2, n, pos_record_count(n), d_isa);
+  auto record_text = [&]() {
+    BWT_LAUNCH("record_text", k_record_text, dim3((unsigned)div_up(pos_record_count(n), 256)), dim3(256), 0, s,
+               d_text2, n, pos_record_count(n), d_isa);
+  };
   // small arrays sit in L2 whatever the order of the stores
   const char *env = getenv("BWT_MI355X_ISA_TWO_STEP");  // for tests on small texts: 1 = one level, 2 = two
   const bool force = env != nullptr, force2 = env && env[0] == '2';
   if (!scratch || (rows <= (1ull << 22) && !force)) {
     BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa);
+    record_text();
     return kOk;
   }
   uint32_t shift = 0;
@@ -280,6 +281,7 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t
   const int xcd_local = (6ull << window_shift) <= (2ull << 20);  // a window of records within half an L2
   BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, filled,
              rows, d_isa, xcd_local);
+  record_text();
   hipError_t e = hipGetLastError();
   if (pairs2 || d_cur2) {
     if (e == hipSuccess) e = hipStreamSynchronize(s);  // before the buffers go back to the pool
