@@ -169,11 +169,10 @@ struct bwtgpu_index {
   // the state of a backward search after its first kmer_k steps, indexed by the
   // string read as a base-4 number (first base most significant).  The interval
   // ends where the next string's starts, less the rows the gap list that follows
-  // the table names (kmer_gaps of them).  A search of a read of at least kmer_k
+  // the table names.  A search of a read of at least kmer_k
   // bases starts there.
   uint32_t *d_kmer = nullptr;
   uint32_t kmer_k = 0;
-  uint32_t kmer_gaps = 0;
   int device = 0;
 };
 

@@ -15,7 +15,6 @@ struct IndexView {
   const uint32_t *text2;
   const uint32_t *kmer;   // null unless the index has the k-mer interval table
   uint32_t kmer_k;
-  uint32_t kmer_gaps;
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
@@ -23,7 +22,7 @@ struct IndexView {
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->kmer_k, ix->kmer_gaps, ix->nsym, ix->n, ix->endloc};
+                   ix->d_kmer,   ix->kmer_k, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {

@@ -485,7 +485,6 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   }
   ix->d_kmer = tab;
   ix->kmer_k = K;
-  ix->kmer_gaps = K - 1;
   return kOk;
 }
 
@@ -646,7 +645,6 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
   ix->kmer_k = 0;
-  ix->kmer_gaps = 0;
   return kOk;
 }
 
