@@ -56,12 +56,17 @@ __device__ __forceinline__ uint32_t text_base2(const IndexView &v, uint32_t p) {
 // (the reversed read of search_reads without a second copy).  pat may point
 // into LDS.
 //
+// hint: what the caller already knows about the last k bases (k the table's
+// string length), used when no trailing N is skipped: 0 nothing, 1 no N among
+// them and hx is their table index, 2 an N among them.
+//
 // at_least: the caller only asks whether the result reaches this length (the
 // anchor test of search_reads); when the table shows that the last k bases do
 // not occur and k <= at_least, the answer is "no" without a single rank query
 // and 0 is returned.  0 asks for the exact value.
 __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int step,
-                                       int len, uint32_t *sp_out, uint32_t *ep_out, int at_least) {
+                                       int len, uint32_t *sp_out, uint32_t *ep_out, int at_least,
+                                       int hint = 0, uint32_t hx = 0) {
   int skips = 0;
   while (len > 0 && pat[(len - 1) * step] == 5) {
     --len;
@@ -77,12 +82,16 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
   int i = len - 2;
   const int K = (int)v.kmer_k;
   if (K && len >= K) {
-    uint32_t x = 0;
-    bool plain = true;
-    for (int k = 0; k < K; ++k) {
-      const uint32_t raw = pat[(len - K + k) * step];
-      plain = plain && raw != 5;
-      x = (x << 2) | (raw & 3u);
+    uint32_t x = hx;
+    bool plain = hint == 1;
+    if (!hint || skips) {
+      x = 0;
+      plain = true;
+      for (int k = 0; k < K; ++k) {
+        const uint32_t raw = pat[(len - K + k) * step];
+        plain = plain && raw != 5;
+        x = (x << 2) | (raw & 3u);
+      }
     }
     if (plain) {
       uint32_t e_sp;
@@ -232,15 +241,40 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
     const uint8_t *p = dir ? bwd : fwd;
     const int step = dir ? bstep : 1;
     int len = full;
+    // the table index of the last K bases is kept from one attempt to the next:
+    // a failed attempt shortens the read by one base, which shifts the window
+    // by one (most attempts on the reversed read fail at the table)
+    const int K = (int)v.kmer_k;
+    int hint = 0, n_in_window = 0;
+    uint32_t hx = 0;
     while (len > anchor) {  // search_reads.c:115
+      if (K && len >= K && !hint) {
+        hx = 0;
+        n_in_window = 0;
+        for (int k = 0; k < K; ++k) {
+          const uint32_t raw = p[(len - K + k) * step];
+          n_in_window += raw == 5;
+          hx = (hx << 2) | (raw & 3u);
+        }
+        hint = n_in_window ? 2 : 1;
+      }
       uint32_t sp, ep;
-      const int got = mms_dev(v, C, p, step, len, &sp, &ep, anchor);
+      const int got = mms_dev(v, C, p, step, len, &sp, &ep, anchor, hint, hx);
       if (got >= anchor) {  // :119-127
         res[dir]++;
         len -= got;
         res[2 + dir] = sp > v.n ? 0xFFFFFFFFu : v.sa ? v.sa[sp] : unc_sa_dev(v, sp);
+        hint = 0;
       } else {
         len -= 1;  // :130
+        if (hint && len >= K) {  // base `len` leaves the window, base len - K enters it
+          const uint32_t in = p[(len - K) * step];
+          n_in_window += (int)(in == 5) - (int)(p[len * step] == 5);
+          hx = (hx >> 2) | ((in & 3u) << (2 * (K - 1)));
+          hint = n_in_window ? 2 : 1;
+        } else {
+          hint = 0;
+        }
       }
     }
   }
