@@ -1,0 +1,127 @@
+"""The single-GPU headline configuration at its full size (46 Mbp, 10 M x 50 bp
+reads): properties that do not need a CPU run of the whole job, plus a
+bit-exact comparison of a sample with the oracle on the index rebuilt from the
+device's own suffix array."""
+import numpy as np
+import pytest
+import torch
+
+from bwt_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N, R, M = 46_000_000, 10_000_000, 50
+
+
+def test_headline_configuration_at_full_size(oracle, gpu):
+    d_text = gpu.gen_genome(N, synth.GENOME_SEED)
+    text = oracle.gen_genome(N, synth.GENOME_SEED)
+    np.testing.assert_array_equal(d_text[: N // 4 + 1].cpu().numpy(), text)  # same generator on both sides
+
+    # the suffix array: a permutation of 0..n in suffix order (O(n) certificate on the host)
+    sa = gpu.sa_build(d_text, N)
+    sa_h = gpu.to_numpy_u32(sa)
+    assert oracle.check_sa(text, N, sa_h) == 0
+    stats = gpu.sa_last_stats()
+    assert stats[2] == 0 and stats[3] == 0  # a random genome never needs the prefix-doubling fallback
+
+    # the index: what make_fmi (seqindex.c:161-189) derives from that suffix array
+    ix = gpu.build_index_dev(d_text, N)
+    fo = oracle.make_fmi(text, N, sa_h)
+    assert ix.endloc == fo.endloc and ix.C == fo.C
+    bwt, idxs = ix.export()
+    np.testing.assert_array_equal(bwt, fo.bwt)
+    np.testing.assert_array_equal(idxs, fo.idxs)
+
+    # the search batch: reads cut from the text at known offsets, 1 % random ones
+    d_reads, d_offs = gpu.gen_reads(d_text, N, R, M, synth.READS_SEED)
+    sp, ep, lr = ix.search(d_reads, M, R, want_locrow=True)
+    offs = gpu.to_numpy_u32(d_offs)
+    cut = offs != 0xFFFFFFFF
+    assert 0.98 < cut.mean() < 0.995
+    sp_h, ep_h, lr_h = (gpu.to_numpy_u32(x) for x in (sp, ep, lr))
+    # every read cut from the text is found, and its interval holds the row of the offset it was cut at
+    assert np.all(ep_h[cut] > sp_h[cut])
+    isa_of_cut = np.empty(N + 1, np.uint32)
+    isa_of_cut[sa_h] = np.arange(N + 1, dtype=np.uint32)
+    rows = isa_of_cut[offs[cut]]
+    assert np.all((sp_h[cut] <= rows) & (rows < ep_h[cut]))
+    # interval size = number of occurrences: every row in it is a suffix that starts with the read
+    bases = synth.unpack(text, N)
+    reads_h = d_reads[: R * M].view(R, M)
+    pick = np.random.default_rng(1).choice(R, 2000, replace=False)
+    pick_reads = reads_h[torch.from_numpy(pick).cuda()].cpu().numpy()
+    for r, read in zip(pick, pick_reads):
+        for row in range(sp_h[r], min(ep_h[r], sp_h[r] + 4)):
+            p = int(sa_h[row])
+            assert p + M <= N and np.array_equal(bases[p:p + M], read)
+    # locate (locate(), seqindex.c:258-277): the position stored for the first row
+    pos = gpu.to_numpy_u32(ix.locate_rows(lr))
+    found = ep_h > sp_h
+    np.testing.assert_array_equal(pos[found], sa_h[sp_h[found]])
+
+    # bit-exact against the oracle's loc_search on a sample that includes the random reads
+    sample = np.concatenate([np.nonzero(~cut)[0][:20000], pick])
+    s_reads = reads_h[torch.from_numpy(sample).cuda()].cpu().numpy()
+    sp_o, ep_o = oracle.search_batch(fo, s_reads, M, M, len(sample))
+    np.testing.assert_array_equal(sp_h[sample], sp_o)
+    np.testing.assert_array_equal(ep_h[sample], ep_o)
+
+    # the index without its optional arrays: every step two rank queries, same answers for all 10 M reads
+    ix.compact()
+    sp2, ep2, lr2 = ix.search(d_reads, M, R, want_locrow=True)
+    assert torch.equal(sp2, sp) and torch.equal(ep2, ep) and torch.equal(lr2, lr)
+    pos2 = gpu.to_numpy_u32(ix.locate_rows(lr2[:1_000_000].contiguous()))
+    np.testing.assert_array_equal(pos2, pos[:1_000_000])
+    ix.close()
+
+
+def test_250_mbp_suffix_array_in_eight_shards(oracle, gpu):
+    """The 8-GPU build configuration on one device: each rank's bucket range
+    sorted on its own (what a rank does), the shards laid side by side, the
+    result certified on the host and equal to the whole build."""
+    from bwt_amd import _lib, dist
+
+    n = 250_000_000
+    d_text = gpu.gen_genome(n, synth.GENOME_SEED)
+    whole = gpu.sa_build(d_text, n)
+    counts = gpu.sa_bucket_counts(d_text, n)
+    ranges = dist.plan_bucket_ranges(counts, 8)
+    rows_of = dist.shard_rows(counts, ranges)
+    assert sum(r for _, r in rows_of) == n  # row 0 (the empty suffix) belongs to no bucket
+    assert max(r for _, r in rows_of) < 1.01 * n / 8
+    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+    sa[0] = n
+    bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+    ws = torch.empty(int(_lib.load().bwtgpu_sa_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    endloc = 0
+    for (lo, hi), (b, r) in zip(ranges, rows_of):
+        begin, rows, e = gpu.sa_build_range(d_text, n, lo, hi, sa[b:b + r], bw[b:b + r], ws)
+        assert (begin, rows) == (b, r)
+        endloc = max(endloc, e)  # reported by the one shard that holds suffix 0
+    assert torch.equal(sa, whole)
+    text = d_text[: n // 4 + 1].cpu().numpy()
+    assert oracle.check_sa(text, n, gpu.to_numpy_u32(sa)) == 0
+    # the index finished from the assembled shards answers like the one built whole
+    del whole, ws
+    ix_whole = gpu.build_index_dev(d_text, n)
+    ix_shards = gpu.build_index_from_sa(d_text, n, sa, bw[1:], endloc)
+    assert ix_shards.endloc == ix_whole.endloc and ix_shards.C == ix_whole.C
+    reads, _ = gpu.gen_reads(d_text, n, 1_000_000, 100, synth.READS_SEED, want_offsets=False)
+    a = ix_whole.search(reads, 100, 1_000_000, want_locrow=True)
+    b = ix_shards.search(reads, 100, 1_000_000, want_locrow=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    ix_whole.close()
+    ix_shards.close()
+
+
+@pytest.mark.parametrize("period,mutations", [(7, 0), (1000, 0), (1000, 5000)], ids=["p7", "p1000", "p1000-mutated"])
+def test_100_mbp_tandem_repeat_suffix_array(oracle, gpu, period, mutations):
+    """Tandem repeats (the input histsort cannot sort, README.md:76-77): the
+    prefix-doubling path at full size, certified on the host."""
+    n = 100_000_000
+    text = synth.gen_tandem(n, period, 11, mutations, 3 if mutations else 0)
+    d_text = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
+    sa = gpu.sa_build(d_text, n)
+    assert gpu.sa_last_stats()[3] > 0  # rounds of prefix doubling were needed
+    assert oracle.check_sa(text, n, gpu.to_numpy_u32(sa)) == 0
