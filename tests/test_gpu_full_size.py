@@ -125,3 +125,33 @@ def test_100_mbp_tandem_repeat_suffix_array(oracle, gpu, period, mutations):
     sa = gpu.sa_build(d_text, n)
     assert gpu.sa_last_stats()[3] > 0  # rounds of prefix doubling were needed
     assert oracle.check_sa(text, n, gpu.to_numpy_u32(sa)) == 0
+
+
+def test_3100_mbp_index_and_search(gpu):
+    """3.1 Gbp, beyond the reference's `int` lengths: no CPU answer exists, so
+    the checks are the ones the text itself provides -- C[4] = n + 1, every read
+    cut from the text found, every unique one located at the offset it was cut
+    at -- and the two search forms (text comparison, rank queries only) against
+    each other."""
+    n, R, m = 3_100_000_000, 20_000_000, 100
+    d_text = gpu.gen_genome(n, synth.GENOME_SEED)
+    ix = gpu.build_index_dev(d_text, n)
+    stats = gpu.sa_last_stats()
+    assert ix.C[0] == 1 and ix.C[4] == n + 1 and 0 < ix.endloc <= n
+    assert stats[2] == 0 and stats[3] == 0
+    reads, offs = gpu.gen_reads(d_text, n, R, m, synth.READS_SEED)
+    sp, ep, lr = ix.search(reads, m, R, want_locrow=True)
+    pos = ix.locate_rows(lr)
+    spn, epn, offn, posn = (gpu.to_numpy_u32(x) for x in (sp, ep, offs, pos))
+    cut = offn != 0xFFFFFFFF
+    assert np.all(epn[cut] > spn[cut])
+    unique = cut & (epn - spn == 1)
+    assert unique.mean() > 0.9
+    np.testing.assert_array_equal(posn[unique], offn[unique])
+    ix.compact()
+    sp2, ep2, lr2 = ix.search(reads, m, R, want_locrow=True)
+    assert torch.equal(sp2, sp) and torch.equal(ep2, ep) and torch.equal(lr2, lr)
+    pos2 = ix.locate_rows(lr2[:2_000_000].contiguous())
+    assert torch.equal(pos2, pos[:2_000_000])
+    ix.close()
+    gpu._lib.load().bwtgpu_release_cache()  # 66 GB of workspace: back to the driver for the tests that follow
