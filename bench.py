@@ -369,6 +369,9 @@ def main():
                 "bound": "hbm", "bytes_per_bp": 5.625,
                 "achieved": 5.625 * n / build_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": 5.625 * n / build_s / 1e9 / HBM_PEAK_GBS,
+                # HBM bytes one build moves over all its kernels (a sort makes several passes), from the
+                # committed PMC passes of this workload
+                "traffic": measured_traffic(f"{n}bp_build"),
             },
             "stats": {"levels": sa_stats[0], "leaves": sa_stats[1], "unresolved_rows": sa_stats[2],
                       "doubling_rounds": sa_stats[3]},
