@@ -269,6 +269,17 @@ def build_index_sharded(d_text, n, group=None):
     return build_index_from_sa(d_text, n, sa, bw[1:], endloc), "sharded"
 
 
+def dp_align_batch(d_s1, d_off1, d_s2, d_off2, R, mode, max_len1, max_len2):
+    """nw_fast (mode 0) / sw_fast (mode 1) for R pairs (see bwtgpu_dp_align_batch).
+    Returns (ret, ops, nops): ops[off1[r] + off2[r] ...] holds pair r's unit operations."""
+    ret = torch.empty(R, dtype=torch.int32, device="cuda")
+    nops = torch.empty(R, dtype=torch.int32, device="cuda")
+    ops = torch.zeros(d_s1.numel() + d_s2.numel() + 1, dtype=torch.uint8, device="cuda")
+    check(_lib.load().bwtgpu_dp_align_batch(_ptr(d_s1), _ptr(d_off1), _ptr(d_s2), _ptr(d_off2), R, mode, max_len1,
+                                            max_len2, _ptr(ret), _ptr(ops), _ptr(nops), _stream()))
+    return ret, ops, nops
+
+
 def sa_last_stats():
     st = (C.c_uint64 * 8)()
     check(_lib.load().bwtgpu_sa_last_stats(st))

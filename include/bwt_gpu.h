@@ -191,6 +191,22 @@ int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64
 int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads,
                         const uint8_t *d_reversed, const uint64_t *d_offsets, uint64_t R,
                         int anchor, uint32_t *d_out, void *stream);
+/* The aligner's dynamic programming for a batch of pairs, one wave per pair:
+ * nw_fast (smw.c:26-111; mode 0) or sw_fast (smw.c:117-200; mode 1) of read
+ * piece r = d_s1[d_off1[r] .. d_off1[r+1]) (bases 0..3, 5 = N, which agrees with
+ * every base) against genome piece r = d_s2[d_off2[r] .. d_off2[r+1]) (bases
+ * 0..3), the way align_read_anchored (single_align.c:196, :238, :267, :294)
+ * calls them.  d_ret[r] = nw_fast's return value (0 for sw_fast).  The CIGAR
+ * goes out as unit operations 'M', 'I', 'D' in the order the reference's
+ * stack_push calls reach the caller's stack (merging runs is stack_push's own
+ * rule, stack.c:62-66): d_nops[r] of them at d_ops + d_off1[r] + d_off2[r].
+ * No piece may be longer than max_len1 / max_len2, which size the launch (a
+ * longer one gets d_nops[r] = 0xFFFFFFFF); 64 KiB of LDS bound them, e.g. 250 x
+ * 260 bases. */
+int bwtgpu_dp_align_batch(const uint8_t *d_s1, const uint64_t *d_off1, const uint8_t *d_s2,
+                          const uint64_t *d_off2, uint64_t R, int mode, uint32_t max_len1,
+                          uint32_t max_len2, int32_t *d_ret, uint8_t *d_ops, uint32_t *d_nops,
+                          void *stream);
 
 /* Occ(c, idx) for R (symbol, index) pairs: seq_rank (seqindex.c:91-111) when
  * skip_dollar_row is 0, rank (seqindex.c:221-225) when it is 1.  Indices

@@ -112,6 +112,7 @@ class Oracle:
         L.orc_locate.argtypes = [fp, u8p, C.c_int]
         L.orc_mms.argtypes = [fp, u8p, C.c_int, u32p, u32p]
         L.orc_search_reads_one.argtypes = [fp, u8p, C.c_int, C.c_int, u32p]
+        L.orc_dp_align.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32p]
         L.orc_search_batch.argtypes = [fp, u8p, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, C.c_int]
         L.orc_locate_rows.argtypes = [fp, u32p, C.c_uint64, u32p, C.POINTER(C.c_uint64), C.c_int]
         L.orc_write_index_path.argtypes = [fp, C.c_char_p]
@@ -214,6 +215,15 @@ class Oracle:
         out = np.zeros(4, np.uint32)
         self.L.orc_search_reads_one(f.ptr, _p(read, u8p), len(read), anchor, _p(out, u32p))
         return out
+
+    def dp_align(self, s1, s2, mode):
+        """nw_fast (mode 0) / sw_fast (mode 1): (return value, unit CIGAR operations as bytes)"""
+        s1 = np.ascontiguousarray(s1, np.uint8)
+        s2 = np.ascontiguousarray(s2, np.uint8)
+        ops = np.zeros(len(s1) + len(s2) + 1, np.uint8)
+        nops = C.c_uint32()
+        ret = self.L.orc_dp_align(_p(s1, u8p), len(s1), _p(s2, u8p), len(s2), mode, _p(ops, u8p), C.byref(nops))
+        return int(ret), ops[: nops.value].tobytes()
 
     def search_batch(self, f, pats, m, stride, R, threads=4):
         pats = np.ascontiguousarray(pats, np.uint8)
@@ -322,6 +332,7 @@ class Reference:
         L.ref_reverse_search_mt.restype = C.c_long
         L.ref_reverse_search_mt.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, C.c_int]
         L.ref_unc_sa_mt.argtypes = [fp, i32p, C.c_long, i32p, C.c_int]
+        L.ref_dp_align.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32p]
         L.ref_write_index_path.argtypes = [fp, C.c_char_p]
         L.ref_read_index_path.restype = fp
         L.ref_read_index_path.argtypes = [C.c_char_p]
@@ -336,6 +347,15 @@ class Reference:
 
     def histsort(self, text, n):
         return self._take(self.L.histsort(_p(text, u8p), n), n + 1)
+
+    def dp_align(self, s1, s2, mode):
+        """the reference's nw_fast (mode 0) / sw_fast (mode 1) on a fresh stack"""
+        s1 = np.ascontiguousarray(s1, np.uint8)
+        s2 = np.ascontiguousarray(s2, np.uint8)
+        ops = np.zeros(len(s1) + len(s2) + 1, np.uint8)
+        nops = C.c_uint32()
+        ret = self.L.ref_dp_align(_p(s1, u8p), len(s1), _p(s2, u8p), len(s2), mode, _p(ops, u8p), C.byref(nops))
+        return int(ret), ops[: nops.value].tobytes()
 
     def csuff_arr(self, text, n):
         return self._take(self.L.csuff_arr(_p(text, u8p), n), n + 1)

@@ -513,6 +513,93 @@ void orc_search_reads_one(const orc_fmi *f, const uint8_t *read, int len, int an
   free(rev);
 }
 
+/* ---- the aligner's dynamic programming (smw.c) ---- */
+
+/* nw_fast (smw.c:26-111; mode 0) and sw_fast (smw.c:117-200; mode 1): one
+ * matrix of scores and one of directions over the read (s1: bases 0..3, 5 = N,
+ * which agrees with every base) and a piece of the genome (s2), scores 0 / -6
+ * for agreement / disagreement and -3 per gap base plus -5 when a gap opens
+ * (:48-54), direction 2 preferred over 1 over 0 on equal scores (:55-62).
+ * Mode 0 ends at the best cell of the last row (first one on ties, :65-70) and
+ * returns that column - 1; mode 1 ends at the last cell and returns 0.
+ * ops receives the unit operations ('M', 'I', 'D') in the order the
+ * reference's stack_push calls reach the caller's stack: the traceback order
+ * for mode 1 (:167-191), its reverse for mode 0 (collected on a second stack
+ * and flipped, :86-107); at most len1 + len2 of them. */
+int orc_dp_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int mode,
+                 uint8_t *ops, uint32_t *nops) {
+  *nops = 0;
+  if (mode == 0 && len1 == 0) return 0; /* smw.c:28-30 */
+  const size_t w = (size_t)len2 + 1;
+  int *val = malloc((size_t)(len1 + 1) * w * sizeof(int));
+  uint8_t *dir = malloc((size_t)(len1 + 1) * w);
+  val[0] = 0;
+  dir[0] = 0; /* never read */
+  for (int j = 1; j <= len2; ++j) {
+    dir[j] = 2;
+    val[j] = -5 - 3 * j;
+  }
+  for (int i = 1; i <= len1; ++i) {
+    dir[i * w] = 1;
+    val[i * w] = -5 - 3 * i;
+    for (int j = 1; j <= len2; ++j) {
+      const int skip2 = dir[i * w + j - 1] == 2 ? 0 : -5;
+      const int skip1 = dir[(i - 1) * w + j] == 1 ? 0 : -5;
+      const int d = val[(i - 1) * w + j - 1] + ((s1[i - 1] == 5 || s1[i - 1] == s2[j - 1]) ? 0 : -6);
+      const int l = val[i * w + j - 1] - 3 + skip2;
+      const int u = val[(i - 1) * w + j] - 3 + skip1;
+      int v = d > l ? d : l;
+      v = v > u ? v : u;
+      val[i * w + j] = v;
+      dir[i * w + j] = v == l ? 2 : v == u ? 1 : 0;
+    }
+  }
+  int i = len1, j = len2, ret = 0;
+  if (mode == 0) {
+    int mx = -1000000, maxloc = 0;
+    for (int q = 0; q <= len2; ++q)
+      if (val[len1 * w + q] > mx) {
+        mx = val[len1 * w + q];
+        maxloc = q;
+      }
+    j = maxloc;
+    ret = maxloc - 1;
+  }
+  uint32_t k = 0;
+  while (i && j) {
+    const uint8_t d = dir[i * w + j];
+    if (d == 1) {
+      --i;
+      ops[k++] = 'I';
+    } else if (d == 2) {
+      --j;
+      ops[k++] = 'D';
+    } else {
+      --i;
+      --j;
+      ops[k++] = 'M';
+    }
+  }
+  while (i) {
+    --i;
+    ops[k++] = 'I';
+  }
+  while (j) {
+    --j;
+    ops[k++] = 'D';
+  }
+  if (mode == 0)
+    for (uint32_t a = 0, b = k; a + 1 < b; ++a, --b) {
+      const uint8_t t = ops[a];
+      ops[a] = ops[b - 1];
+      ops[b - 1] = t;
+    }
+  *nops = k;
+  free(val);
+  free(dir);
+  return ret;
+}
+
 /* ---- threaded batch drivers (fmitest.c:54-91: static contiguous split) ---- */
 
 typedef struct {

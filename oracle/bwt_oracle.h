@@ -105,6 +105,11 @@ int      orc_mms(const orc_fmi *f, const uint8_t *pat, int m,
  * backward position (0xFFFFFFFF: none) */
 void orc_search_reads_one(const orc_fmi *f, const uint8_t *read, int len, int anchor,
                           uint32_t out[4]);
+/* nw_fast (mode 0) / sw_fast (mode 1) of smw.c: returns what nw_fast returns
+ * (0 for mode 1); ops[0..*nops) are the unit CIGAR operations in the order they
+ * reach the caller's stack. */
+int orc_dp_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int mode,
+                 uint8_t *ops, uint32_t *nops);
 
 /* batch drivers used for cpu_baseline timing: threads pthreads, each a
  * contiguous slice (fmitest.c:67-91) */

@@ -12,6 +12,8 @@
 
 #include "seqindex.h"
 #include "fileio.h"
+#include "smw.h"
+#include "stack.h"
 
 typedef struct {
   const fm_index *fmi;
@@ -104,4 +106,20 @@ void ref_copy_rank_rows(const fm_index *fmi, int *out) {
   long rows = 1 + ((long)fmi->len + 15) / 16;
   for (long j = 0; j < rows; ++j)
     for (int c = 0; c < 4; ++c) out[4 * j + c] = fmi->rank_index[j][c];
+}
+
+/* nw_fast (mode 0) / sw_fast (mode 1) on a fresh stack; the stack's runs are
+ * written out as unit operations, first pushed first. */
+int ref_dp_align(const char *s1, int len1, const char *s2, int len2, int mode,
+                 unsigned char *ops, unsigned *nops) {
+  stack *s = stack_make();
+  int ret = 0;
+  if (mode == 0) ret = nw_fast(s1, len1, s2, len2, s);
+  else sw_fast(s1, len1, s2, len2, s);
+  unsigned k = 0;
+  for (int e = 0; e < s->size; ++e)
+    for (int c = 0; c < s->counts[e]; ++c) ops[k++] = (unsigned char)s->chars[e];
+  *nops = k;
+  stack_destroy(s);
+  return ret;
 }

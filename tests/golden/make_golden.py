@@ -3,7 +3,7 @@
 
 The reference ships no golden outputs (its tests are self-checks and cycle
 counters), so every vector here comes from oracle/_ref/libbwtref.so -- the
-reference's own histsortcomp.c, csacak.c, seqindex.c and fileio.c compiled by
+reference's own histsortcomp.c, csacak.c, seqindex.c, fileio.c, smw.c and stack.c compiled by
 oracle/Makefile from where they lie -- driven on inputs from the seeded
 generators of the oracle.  Only hashes and tiny vectors are stored; the inputs
 are regenerated from their seeds by the tests.
@@ -153,6 +153,16 @@ def main():
     f = ref.make_fmi(packed, len(ascii_text), sacak=True)
     G["packer_1003"] = {"ascii": ascii_text.decode("latin-1"), "packed": sha(packed),
                         **fmi_record(ref, f)}
+
+    # 6. the aligner's dynamic programming: nw_fast / sw_fast (smw.c) on seeded pairs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import dp_cases, dp_digest  # the generator the tests use (reads the previous golden.json on import)
+    G["dp"] = []
+    for mode in (0, 1):
+        seed, count, max1, max2 = 7100 + mode, 1200, 90, 100
+        res = [ref.dp_align(s1, g, mode) for s1, g in dp_cases(seed, count, max1, max2)]
+        G["dp"].append({"mode": mode, "seed": seed, "count": count, "max1": max1, "max2": max2,
+                        "first": [[r, o.decode()] for r, o in res[:12]], "sha256": dp_digest(res)})
 
     out = os.path.join(ROOT, "tests", "golden", "golden.json")
     with open(out, "w") as fp:

@@ -37,3 +37,46 @@ def mms_patterns(orc, text, n, count, m, seed):
 
 def probe_rows(rec):
     return np.arange(rec["probe_rows"], dtype=np.uint32) * rec["probe_rows_step"]
+
+
+def dp_cases(seed, count, max1, max2):
+    """(read piece, genome piece) pairs of the kinds align_read_anchored makes:
+    a read piece that is the genome piece with substitutions, insertions,
+    deletions and Ns, pieces of unrelated bases, empty and one-base pieces."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(count):
+        l2 = int(rng.integers(0, max2 + 1))
+        g = rng.integers(0, 4, l2).astype(np.uint8)
+        kind = it % 6
+        if kind == 0:
+            s1 = rng.integers(0, 4, int(rng.integers(0, max1 + 1))).astype(np.uint8)
+        else:
+            s = list(g[: max(0, l2 - int(rng.integers(0, 12)))])
+            for _ in range(int(rng.integers(0, 5))):
+                if not s:
+                    break
+                p = int(rng.integers(0, len(s)))
+                what = int(rng.integers(0, 4))
+                if what == 0:
+                    s[p] = (s[p] + 1 + int(rng.integers(0, 3))) & 3
+                elif what == 1:
+                    del s[p: p + int(rng.integers(1, 4))]
+                elif what == 2:
+                    s[p:p] = list(rng.integers(0, 4, int(rng.integers(1, 4))))
+                else:
+                    s[p] = 5
+            s1 = np.array(s[:max1], np.uint8)
+        if kind == 5:
+            s1 = s1[::-1].copy()
+        out.append((s1, g))
+    out += [(np.zeros(0, np.uint8), np.zeros(0, np.uint8)), (np.array([2], np.uint8), np.zeros(0, np.uint8)),
+            (np.zeros(0, np.uint8), np.array([1, 1, 3], np.uint8)), (np.array([5], np.uint8), np.array([3], np.uint8))]
+    return out
+
+
+def dp_digest(results):
+    """one hash over (return value, operations) of a list of dp_align results"""
+    import hashlib
+
+    return hashlib.sha256(";".join(f"{r}:{o.decode()}" for r, o in results).encode()).hexdigest()
