@@ -14,6 +14,12 @@
 
 namespace bwtgpu {
 
+// the value lane l - 1 holds, in lane l (lane 0 keeps its own): one DPP move
+// across the whole wave instead of a trip through the LDS crossbar
+__device__ __forceinline__ int wave_shift_up(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+
 struct DpLds {
   uint32_t s1, dirs, edge_v, edge_p, ops, total;  // byte offsets
   uint32_t words_per_col;
@@ -63,6 +69,11 @@ k_dp_align(const uint8_t *__restrict__ s1_all, const uint64_t *__restrict__ off1
     return;
   }
   for (int i = (int)lane; i < len1; i += 64) s1[i] = s1_all[a1 + i];
+  // column 0 (smw.c:37, :44-45) is what the first strip finds to its left
+  for (int i = (int)lane; i <= len1; i += 64) {
+    edge_v[i] = i ? -5 - 3 * i : 0;
+    edge_p[i] = 1;
+  }
   __syncthreads();
   const uint32_t W = L.words_per_col;
   int best_v = -5 - 3 * len1, best_j = 0;  // column 0 of the last row (smw.c:45, :65-70)
@@ -72,43 +83,47 @@ k_dp_align(const uint8_t *__restrict__ s1_all, const uint64_t *__restrict__ off1
     const int lanes = len2 - j0 + 1 < 64 ? len2 - j0 + 1 : 64;
     const uint32_t c2 = col ? s2_all[a2 + j - 1] : 0u;
     int vc = -5 - 3 * j, vp = 0;  // row 0 (smw.c:38-41)
-    uint32_t pc = 2, pw = 0;
-    const int steps = len1 + lanes - 1;
+    uint32_t pc = 2, pw = 0, c1 = 0;
+    int ev_prev = edge_v[0];  // the column to the left, one row up
+    const int steps = len1 ? len1 + lanes - 1 : 0;  // sw_fast of an empty read has no cells
     for (int t = 1; t <= steps; ++t) {
       const int i = t - (int)lane;
-      int lv = __shfl_up(vc, 1, 64), dv = __shfl_up(vp, 1, 64);
-      uint32_t lp = __shfl_up(pc, 1, 64);
+      // what the lane to the left held after the previous step: its cell of this
+      // row, that cell's direction, its cell one row up, and the read base of this
+      // row (the same base travels down the anti-diagonal)
+      int lv = wave_shift_up(vc), dv = wave_shift_up(vp);
+      uint32_t lp = (uint32_t)wave_shift_up((int)pc);
+      c1 = (uint32_t)wave_shift_up((int)c1);
+      // the first lane takes them from the column left of the strip (one address for the whole wave)
+      const int te = t <= len1 ? t : len1;
+      const int ev = edge_v[te];
+      const uint32_t ep = edge_p[te];
+      const uint32_t cb = s1[te - 1];
       if (lane == 0) {
-        if (j0 == 1) {  // column 0 (smw.c:44-45)
-          lv = -5 - 3 * i;
-          lp = 1;
-          dv = i == 1 ? 0 : -5 - 3 * (i - 1);
-        } else if (i >= 1 && i <= len1) {
-          lv = edge_v[i];
-          lp = edge_p[i];
-          dv = edge_v[i - 1];
-        }
+        lv = ev;
+        lp = ep;
+        dv = ev_prev;
+        c1 = cb;
       }
-      if (col && i >= 1 && i <= len1) {
-        const uint32_t c1 = s1[i - 1];
-        const int d = dv + ((c1 == 5u || c1 == c2) ? 0 : -6);  // smw.c:52
-        const int l = lv - 3 + (lp == 2u ? 0 : -5);             // :48, :53
-        const int u = vc - 3 + (pc == 1u ? 0 : -5);             // :49, :54
-        int v = d > l ? d : l;
-        v = v > u ? v : u;
-        const uint32_t p = v == l ? 2u : v == u ? 1u : 0u;      // :55-62
-        vp = vc;
-        vc = v;
-        pc = p;
-        pw |= p << (2 * (i & 15));
-        if ((i & 15) == 15 || i == len1) {
-          dirs[(uint32_t)(j - 1) * W + (uint32_t)(i >> 4)] = pw;
-          pw = 0;
-        }
-        if (lane == 63) {  // rows t - 63 and below are behind the first lane, which reads rows t and t - 1
-          edge_v[i] = v;
-          edge_p[i] = p;
-        }
+      ev_prev = ev;
+      const bool cell = col && i >= 1 && i <= len1;
+      const int d = dv + ((c1 == 5u || c1 == c2) ? 0 : -6);  // smw.c:52
+      const int l = lv - 3 + (lp == 2u ? 0 : -5);             // :48, :53
+      const int u = vc - 3 + (pc == 1u ? 0 : -5);             // :49, :54
+      int v = d > l ? d : l;
+      v = v > u ? v : u;
+      const uint32_t p = v == l ? 2u : v == u ? 1u : 0u;      // :55-62
+      vp = cell ? vc : vp;
+      vc = cell ? v : vc;
+      pc = cell ? p : pc;
+      pw |= cell ? p << (2 * (i & 15)) : 0u;
+      if (cell && ((i & 15) == 15 || i == len1)) {
+        dirs[(uint32_t)(j - 1) * W + (uint32_t)(i >> 4)] = pw;
+        pw = 0;
+      }
+      if (cell && lane == 63) {  // rows t - 63 and below are behind the first lane, which reads row t
+        edge_v[i] = v;
+        edge_p[i] = p;
       }
     }
     // the last row: the first best cell wins (smw.c:65-70)
