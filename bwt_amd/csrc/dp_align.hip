@@ -1,41 +1,9 @@
-// The aligner's dynamic programming (nw_fast, smw.c:26-111, and sw_fast,
-// smw.c:117-200) for a batch of (read piece, genome piece) pairs: one wave per
-// pair.
-//
-// The matrix is swept in strips of 64 columns.  Lane l of a strip owns column
-// j0 + l and at step t fills row t - l, so the cells of one step lie on an
-// anti-diagonal and need only what the lane to the left held one step (left
-// neighbour, its direction) and two steps (diagonal neighbour) earlier: three
-// lane shifts, no memory.  The last lane of a strip leaves its column in LDS for
-// the first lane of the next strip.  Directions (2 bits a cell) are packed by
-// each lane along its own column, sixteen rows to a word, and go to LDS for the
-// traceback, which one wave walks serially.
+// nw_fast / sw_fast (smw.c:26-200) for a batch of (read piece, genome piece)
+// pairs, one wave per pair: see dp_device.hpp.
 #include "common.hpp"
+#include "dp_device.hpp"
 
 namespace bwtgpu {
-
-// the value lane l - 1 holds, in lane l (lane 0 keeps its own): one DPP move
-// across the whole wave instead of a trip through the LDS crossbar
-__device__ __forceinline__ int wave_shift_up(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-}
-
-struct DpLds {
-  uint32_t s1, dirs, edge_v, edge_p, ops, total;  // byte offsets
-  uint32_t words_per_col;
-};
-
-static DpLds dp_lds_layout(uint32_t max1, uint32_t max2) {
-  DpLds L;
-  L.words_per_col = (max1 + 1 + 15) / 16;
-  L.s1 = 0;
-  L.dirs = (uint32_t)align_up(max1 + 1, 4);
-  L.edge_v = L.dirs + max2 * L.words_per_col * 4;
-  L.edge_p = L.edge_v + (max1 + 1) * 4;
-  L.ops = L.edge_p + (max1 + 1) * 4;
-  L.total = L.ops + (uint32_t)align_up((size_t)max1 + max2 + 1, 4);
-  return L;
-}
 
 __global__ void __launch_bounds__(64)
 k_dp_align(const uint8_t *__restrict__ s1_all, const uint64_t *__restrict__ off1,
@@ -43,16 +11,11 @@ k_dp_align(const uint8_t *__restrict__ s1_all, const uint64_t *__restrict__ off1
            uint32_t max2, DpLds L, int32_t *__restrict__ ret, uint8_t *__restrict__ ops_all,
            uint32_t *__restrict__ nops) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  uint8_t *s1 = lds + L.s1;
-  uint32_t *dirs = reinterpret_cast<uint32_t *>(lds + L.dirs);
-  int *edge_v = reinterpret_cast<int *>(lds + L.edge_v);
-  uint32_t *edge_p = reinterpret_cast<uint32_t *>(lds + L.edge_p);
-  uint8_t *ops = lds + L.ops;
+  uint8_t *s1 = lds + L.total;  // the read piece, behind the wave's matrix area
   const uint64_t r = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   const uint64_t a1 = off1[r], a2 = off2[r];
   const uint64_t l1 = off1[r + 1] - a1, l2 = off2[r + 1] - a2;
-  uint8_t *out = ops_all + a1 + a2;
   if (l1 > max1 || l2 > max2) {  // not what the launch was sized for
     if (lane == 0) {
       ret[r] = 0;
@@ -61,118 +24,14 @@ k_dp_align(const uint8_t *__restrict__ s1_all, const uint64_t *__restrict__ off1
     return;
   }
   const int len1 = (int)l1, len2 = (int)l2;
-  if (mode == 0 && len1 == 0) {  // smw.c:28-30
-    if (lane == 0) {
-      ret[r] = 0;
-      nops[r] = 0;
-    }
-    return;
-  }
   for (int i = (int)lane; i < len1; i += 64) s1[i] = s1_all[a1 + i];
-  // column 0 (smw.c:37, :44-45) is what the first strip finds to its left
-  for (int i = (int)lane; i <= len1; i += 64) {
-    edge_v[i] = i ? -5 - 3 * i : 0;
-    edge_p[i] = 1;
-  }
   __syncthreads();
-  const uint32_t W = L.words_per_col;
-  int best_v = -5 - 3 * len1, best_j = 0;  // column 0 of the last row (smw.c:45, :65-70)
-  for (int j0 = 1; j0 <= len2; j0 += 64) {
-    const int j = j0 + (int)lane;
-    const bool col = j <= len2;
-    const int lanes = len2 - j0 + 1 < 64 ? len2 - j0 + 1 : 64;
-    const uint32_t c2 = col ? s2_all[a2 + j - 1] : 0u;
-    int vc = -5 - 3 * j, vp = 0;  // row 0 (smw.c:38-41)
-    uint32_t pc = 2, pw = 0, c1 = 0;
-    int ev_prev = edge_v[0];  // the column to the left, one row up
-    const int steps = len1 ? len1 + lanes - 1 : 0;  // sw_fast of an empty read has no cells
-    for (int t = 1; t <= steps; ++t) {
-      const int i = t - (int)lane;
-      // what the lane to the left held after the previous step: its cell of this
-      // row, that cell's direction, its cell one row up, and the read base of this
-      // row (the same base travels down the anti-diagonal)
-      int lv = wave_shift_up(vc), dv = wave_shift_up(vp);
-      uint32_t lp = (uint32_t)wave_shift_up((int)pc);
-      c1 = (uint32_t)wave_shift_up((int)c1);
-      // the first lane takes them from the column left of the strip (one address for the whole wave)
-      const int te = t <= len1 ? t : len1;
-      const int ev = edge_v[te];
-      const uint32_t ep = edge_p[te];
-      const uint32_t cb = s1[te - 1];
-      if (lane == 0) {
-        lv = ev;
-        lp = ep;
-        dv = ev_prev;
-        c1 = cb;
-      }
-      ev_prev = ev;
-      const bool cell = col && i >= 1 && i <= len1;
-      const int d = dv + ((c1 == 5u || c1 == c2) ? 0 : -6);  // smw.c:52
-      const int l = lv - 3 + (lp == 2u ? 0 : -5);             // :48, :53
-      const int u = vc - 3 + (pc == 1u ? 0 : -5);             // :49, :54
-      int v = d > l ? d : l;
-      v = v > u ? v : u;
-      const uint32_t p = v == l ? 2u : v == u ? 1u : 0u;      // :55-62
-      vp = cell ? vc : vp;
-      vc = cell ? v : vc;
-      pc = cell ? p : pc;
-      pw |= cell ? p << (2 * (i & 15)) : 0u;
-      if (cell && ((i & 15) == 15 || i == len1)) {
-        dirs[(uint32_t)(j - 1) * W + (uint32_t)(i >> 4)] = pw;
-        pw = 0;
-      }
-      if (cell && lane == 63) {  // rows t - 63 and below are behind the first lane, which reads row t
-        edge_v[i] = v;
-        edge_p[i] = p;
-      }
-    }
-    // the last row: the first best cell wins (smw.c:65-70)
-    int cv = col ? vc : -2000000, cj = j;
-    if (len1 == 0) cv = col ? -5 - 3 * j : -2000000;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int ov = __shfl_xor(cv, off, 64), oj = __shfl_xor(cj, off, 64);
-      if (ov > cv || (ov == cv && oj < cj)) {
-        cv = ov;
-        cj = oj;
-      }
-    }
-    if (cv > best_v) {
-      best_v = cv;
-      best_j = cj;
-    }
-    __syncthreads();
-    if (lane == 0) edge_v[0] = -5 - 3 * (j0 + 63);  // row 0 of the column the next strip starts from
-    __syncthreads();
-  }
-  // traceback (smw.c:71-107, :154-191): every lane walks the same path, lane 0 writes it down
-  int i = len1, j = mode == 0 ? best_j : len2;
   uint32_t k = 0;
-  while (i && j) {
-    const uint32_t p = (dirs[(uint32_t)(j - 1) * W + (uint32_t)(i >> 4)] >> (2 * (i & 15))) & 3u;
-    uint8_t ch;
-    if (p == 1u) {
-      --i;
-      ch = 'I';
-    } else if (p == 2u) {
-      --j;
-      ch = 'D';
-    } else {
-      --i;
-      --j;
-      ch = 'M';
-    }
-    if (lane == 0) ops[k] = ch;
-    ++k;
-  }
-  for (; i; --i, ++k)
-    if (lane == 0) ops[k] = 'I';
-  for (; j; --j, ++k)
-    if (lane == 0) ops[k] = 'D';
-  __syncthreads();
-  // mode 0 collects the path on a second stack and flips it onto the caller's (smw.c:86-107)
-  for (uint32_t q = lane; q < k; q += 64) out[q] = mode == 0 ? ops[k - 1 - q] : ops[q];
+  const uint8_t *s2 = s2_all + a2;
+  const int rv = dp_wave([&](int i) -> uint32_t { return s1[i]; }, len1,
+                         [&](int j) -> uint32_t { return s2[j]; }, len2, mode, L, lds, ops_all + a1 + a2, &k);
   if (lane == 0) {
-    ret[r] = mode == 0 ? best_j - 1 : 0;
+    ret[r] = rv;
     nops[r] = k;
   }
 }
@@ -192,10 +51,11 @@ extern "C" int bwtgpu_dp_align_batch(const uint8_t *d_s1, const uint64_t *d_off1
   if (R > 0x7FFFFFFFull) return set_error(kErrArg, "too many pairs for one launch");
   if (max_len1 > 65535u || max_len2 > 65535u) return set_error(kErrArg, "pieces of up to 65535 bases");
   const DpLds L = dp_lds_layout(max_len1, max_len2);
-  if (L.total > 64u * 1024u)
+  const uint32_t lds_bytes = L.total + (uint32_t)align_up(max_len1 + 1, 4);
+  if (lds_bytes > 64u * 1024u)
     return set_error(kErrArg, "pieces of %u x %u bases need %u bytes of LDS (64 KiB at most)", max_len1, max_len2,
-                     L.total);
-  BWT_LAUNCH("dp_align", k_dp_align, dim3((unsigned)R), dim3(64), L.total, (hipStream_t)stream, d_s1, d_off1,
+                     lds_bytes);
+  BWT_LAUNCH("dp_align", k_dp_align, dim3((unsigned)R), dim3(64), lds_bytes, (hipStream_t)stream, d_s1, d_off1,
              d_s2, d_off2, mode, max_len1, max_len2, L, d_ret, d_ops, d_nops);
   BWT_CHECK_LAUNCH();
   return kOk;

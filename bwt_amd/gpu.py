@@ -280,6 +280,17 @@ def dp_align_batch(d_s1, d_off1, d_s2, d_off2, R, mode, max_len1, max_len2):
     return ret, ops, nops
 
 
+def align_reads(ix, d_text, d_reads, d_offsets, R, anchor_len, max_len):
+    """align_read_anchored for R reads (see bwtgpu_align_reads).  Returns (pos, ops, nops):
+    ops[5 * offsets[r] + 64 * r ...] holds read r's unit operations, first pushed first."""
+    pos = torch.empty(R, dtype=torch.int32, device="cuda")
+    nops = torch.empty(R, dtype=torch.int32, device="cuda")
+    ops = torch.zeros(5 * d_reads.numel() + 64 * R + 64, dtype=torch.uint8, device="cuda")
+    check(_lib.load().bwtgpu_align_reads(ix.h, _ptr(d_text), _ptr(d_reads), _ptr(d_offsets), R, anchor_len,
+                                         max_len, _ptr(pos), _ptr(ops), _ptr(nops), _stream()))
+    return pos, ops, nops
+
+
 def sa_last_stats():
     st = (C.c_uint64 * 8)()
     check(_lib.load().bwtgpu_sa_last_stats(st))

@@ -207,6 +207,25 @@ int bwtgpu_dp_align_batch(const uint8_t *d_s1, const uint64_t *d_off1, const uin
                           const uint64_t *d_off2, uint64_t R, int mode, uint32_t max_len1,
                           uint32_t max_len2, int32_t *d_ret, uint8_t *d_ops, uint32_t *d_nops,
                           void *stream);
+/* align_read_anchored (single_align.c:163-298) for a batch of reads, one wave
+ * per read: anchors by mms, the anchor extended backwards over gaps of up to
+ * nine bases, nw_fast on the read's tail and head, sw_fast between anchors.
+ * d_text is the packed text the index was built from (the reference's `seq`
+ * argument); read r is the encoded bytes d_reads[d_offsets[r] .. d_offsets[r+1])
+ * (0..3, 5 = N; single_align.c:450-474), none longer than max_len (about 380
+ * bases fit the 64 KiB of LDS).  d_pos[r] = the function's return value (0:
+ * not aligned; single_align.c:484-486 prints it + 1).  The CIGAR stack is
+ * returned as unit operations 'M', 'I', 'D', first pushed first
+ * (stack_print_destroy, stack.c:27-37, prints from the other end): d_nops[r]
+ * of them at d_ops + 5 * d_offsets[r] + 64 * r.  d_nops[r] = 0xFFFFFFFF marks a
+ * read longer than max_len.  Two things the reference leaves undefined are
+ * defined here: a read of at most anchor_len bases returns 0 (the reference
+ * reads an unset variable, single_align.c:281), and where it calls mms on no
+ * bases (fewer than ten bases left in front of an anchor, :215) d_pos[r] is
+ * INT_MIN. */
+int bwtgpu_align_reads(const bwtgpu_index *ix, const uint8_t *d_text, const uint8_t *d_reads,
+                       const uint64_t *d_offsets, uint64_t R, int anchor_len, uint32_t max_len,
+                       int32_t *d_pos, uint8_t *d_ops, uint32_t *d_nops, void *stream);
 
 /* Occ(c, idx) for R (symbol, index) pairs: seq_rank (seqindex.c:91-111) when
  * skip_dollar_row is 0, rank (seqindex.c:221-225) when it is 1.  Indices

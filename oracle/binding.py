@@ -113,6 +113,7 @@ class Oracle:
         L.orc_mms.argtypes = [fp, u8p, C.c_int, u32p, u32p]
         L.orc_search_reads_one.argtypes = [fp, u8p, C.c_int, C.c_int, u32p]
         L.orc_dp_align.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32p]
+        L.orc_align_read_anchored.argtypes = [fp, u8p, u8p, C.c_int, C.c_int, u8p, u32p]
         L.orc_search_batch.argtypes = [fp, u8p, C.c_uint32, C.c_uint64, C.c_uint64, u32p, u32p, C.c_int]
         L.orc_locate_rows.argtypes = [fp, u32p, C.c_uint64, u32p, C.POINTER(C.c_uint64), C.c_int]
         L.orc_write_index_path.argtypes = [fp, C.c_char_p]
@@ -215,6 +216,17 @@ class Oracle:
         out = np.zeros(4, np.uint32)
         self.L.orc_search_reads_one(f.ptr, _p(read, u8p), len(read), anchor, _p(out, u32p))
         return out
+
+    ALIGN_UNDEFINED = -2 ** 31
+
+    def align_read_anchored(self, f, text, pattern, anchor_len=12):
+        """align_read_anchored (single_align.c:163-298): (position or 0, unit CIGAR operations in push order)"""
+        pattern = np.ascontiguousarray(pattern, np.uint8)
+        ops = np.zeros(5 * len(pattern) + 64, np.uint8)
+        nops = C.c_uint32()
+        pos = self.L.orc_align_read_anchored(f.ptr, _p(text, u8p), _p(pattern, u8p), len(pattern), anchor_len,
+                                             _p(ops, u8p), C.byref(nops))
+        return int(pos), ops[: nops.value].tobytes()
 
     def dp_align(self, s1, s2, mode):
         """nw_fast (mode 0) / sw_fast (mode 1): (return value, unit CIGAR operations as bytes)"""
@@ -333,6 +345,7 @@ class Reference:
         L.ref_reverse_search_mt.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, C.c_int]
         L.ref_unc_sa_mt.argtypes = [fp, i32p, C.c_long, i32p, C.c_int]
         L.ref_dp_align.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, u32p]
+        L.ref_align_read_anchored.argtypes = [fp, u8p, u8p, C.c_int, C.c_int, u8p, u32p]
         L.ref_write_index_path.argtypes = [fp, C.c_char_p]
         L.ref_read_index_path.restype = fp
         L.ref_read_index_path.argtypes = [C.c_char_p]
@@ -347,6 +360,15 @@ class Reference:
 
     def histsort(self, text, n):
         return self._take(self.L.histsort(_p(text, u8p), n), n + 1)
+
+    def align_read_anchored(self, f, text, pattern, anchor_len=12):
+        """the reference's align_read_anchored on a fresh stack, as single_align.c:479-483 calls it"""
+        pattern = np.ascontiguousarray(pattern, np.uint8)
+        ops = np.zeros(5 * len(pattern) + 64, np.uint8)
+        nops = C.c_uint32()
+        pos = self.L.ref_align_read_anchored(f.ptr, _p(text, u8p), _p(pattern, u8p), len(pattern), anchor_len,
+                                             _p(ops, u8p), C.byref(nops))
+        return int(pos), ops[: nops.value].tobytes()
 
     def dp_align(self, s1, s2, mode):
         """the reference's nw_fast (mode 0) / sw_fast (mode 1) on a fresh stack"""

@@ -600,6 +600,155 @@ int orc_dp_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int m
   return ret;
 }
 
+/* ---- align_read_anchored (single_align.c:163-298) ---- */
+
+/* The caller's CIGAR stack as the list of unit operations pushed so far
+ * (stack_push merges runs, stack.c:62-66, which leaves the unit sequence
+ * unchanged). */
+typedef struct {
+  uint8_t *ops;
+  uint32_t n, cap;
+} opstack;
+
+static void ops_push(opstack *s, uint8_t c, int count) {
+  for (int k = 0; k < count; ++k) {
+    if (s->n == s->cap) {
+      s->cap = s->cap ? 2 * s->cap : 256;
+      s->ops = realloc(s->ops, s->cap);
+    }
+    s->ops[s->n++] = c;
+  }
+}
+
+static void ops_dp(opstack *s, const uint8_t *s1, int len1, const uint8_t *s2, int len2, int mode, int *ret) {
+  uint8_t *tmp = malloc((size_t)len1 + len2 + 1);
+  uint32_t k = 0;
+  const int r = orc_dp_align(s1, len1, s2, len2, mode, tmp, &k);
+  for (uint32_t q = 0; q < k; ++q) ops_push(s, tmp[q], 1);
+  free(tmp);
+  if (ret) *ret = r;
+}
+
+static unsigned align_base(const uint8_t *text, int64_t idx) { /* single_align.c:19-23 */
+  return orc_getbase(text, idx < 0 ? 0 : (uint64_t)idx);
+}
+
+/* single_align.c:163-298.  Returns the position the function returns (0: not
+ * aligned); ops[0..*nops) are the unit CIGAR operations left on the stack,
+ * first pushed first.  Two places where the reference's behaviour is undefined
+ * are given a definition here and reported: a read of at most anchor_len bases
+ * (nmisses is read uninitialised, :281) returns 0, and an mms call on no bases
+ * or fewer (len - curgap <= 0, :215) ends the alignment with ORC_ALIGN_UNDEFINED. */
+int orc_align_read_anchored(const orc_fmi *f, const uint8_t *text, const uint8_t *pattern, int len,
+                            int anchor_len, uint8_t *ops_out, uint32_t *nops) {
+  opstack st = {NULL, 0, 0};
+  const int olen = len;
+  int anchmisses = len / 10, nmisses = 0;
+  int curgap = 0, anchlen = 0, result = 0;
+  int64_t curpos = -1;
+  int done = 0;
+  while (len > anchor_len && anchmisses > 0 && !done) {
+    nmisses = 0;
+    while (len > anchor_len && anchmisses > 0) { /* :175-206 */
+      uint32_t sp, ep;
+      const int seglen = orc_mms(f, pattern, len, &sp, &ep);
+      if (seglen < anchor_len || (int64_t)ep - (int64_t)sp > 1) {
+        anchmisses--;
+        len -= 3;
+        continue;
+      }
+      len -= seglen;
+      anchlen = seglen;
+      nmisses = olen / 5;
+      curpos = orc_unc_sa(f, sp, NULL);
+      int buflen = 10 + (olen - (len + seglen));
+      if ((int64_t)buflen + curpos + seglen > (int64_t)f->len) buflen = (int)((int64_t)f->len - curpos - seglen);
+      uint8_t *buf = malloc(buflen > 0 ? (size_t)buflen : 1);
+      for (int i = 0; i < buflen; ++i) buf[i] = (uint8_t)align_base(text, curpos + seglen + i);
+      ops_dp(&st, pattern + len + seglen, olen - (len + seglen), buf, buflen, 0, NULL);
+      free(buf);
+      ops_push(&st, 'M', seglen);
+      break;
+    }
+    if (nmisses < 1) continue;
+    while (len > nmisses && len > 4 && nmisses > 0 && !done) { /* :212-255 */
+      for (curgap = 1; curgap < 10; ++curgap) {
+        if (len - curgap <= 0) {
+          result = ORC_ALIGN_UNDEFINED;
+          done = 1;
+          break;
+        }
+        uint32_t start, end;
+        const int seglen = orc_mms(f, pattern, len - curgap, &start, &end);
+        int matched = 0;
+        for (uint32_t i = start; i < end; ++i) {
+          const int64_t here = orc_unc_sa(f, i, NULL);
+          int64_t dist = here + seglen - curpos;
+          if (dist < 0) dist = -dist;
+          if (dist - curgap <= 3) {
+            nmisses -= curgap;
+            matched = 1;
+            const int64_t buflen = curpos - (here + seglen);
+            if (buflen < 0) {
+              ops_push(&st, 'I', (int)-buflen);
+            } else {
+              uint8_t *buf = malloc(buflen > 0 ? (size_t)buflen : 1);
+              for (int64_t j = 0; j < buflen; ++j) buf[j] = (uint8_t)align_base(text, here + seglen + j);
+              ops_dp(&st, pattern + (len - curgap), curgap, buf, (int)buflen, 1, NULL);
+              free(buf);
+            }
+            ops_push(&st, 'M', seglen);
+            curpos = here;
+            len -= seglen + curgap;
+            curgap = 0;
+            break;
+          }
+        }
+        if (matched) break;
+      }
+      if (done) break;
+      if (curgap) nmisses = 0;
+    }
+    if (done) break;
+    if (nmisses > 0) { /* :256-272 */
+      int buflen = len + 10;
+      if (buflen > curpos) buflen = (int)curpos;
+      uint8_t *buf = malloc(buflen > 0 ? (size_t)buflen : 1), *buf2 = malloc(len > 0 ? (size_t)len : 1);
+      for (int i = 0; i < buflen; ++i) buf[i] = (uint8_t)align_base(text, curpos - 1 - i);
+      for (int i = 0; i < len; ++i) buf2[i] = pattern[len - 1 - i];
+      int x = 0;
+      ops_dp(&st, buf2, len, buf, buflen, 0, &x);
+      free(buf);
+      free(buf2);
+      result = (int)(curpos - x);
+      done = 2;
+      break;
+    }
+    len -= anchlen;
+    anchmisses -= anchlen / 10;
+    st.n = 0; /* :279 */
+  }
+  if (!done) {
+    if (len > nmisses || nmisses < 1) { /* :281-283 */
+      result = 0;
+    } else {
+      int buflen = len + 10;
+      if (buflen > curpos) buflen = (int)curpos;
+      uint8_t *buf = malloc(buflen > 0 ? (size_t)buflen : 1), *buf2 = malloc(len > 0 ? (size_t)len : 1);
+      for (int i = 0; i < buflen; ++i) buf[i] = (uint8_t)align_base(text, curpos - 1 - i);
+      for (int i = 0; i < len; ++i) buf2[i] = pattern[len - 1 - i];
+      ops_dp(&st, buf2, len, buf, buflen, 0, NULL);
+      free(buf);
+      free(buf2);
+      result = (int)(curpos - len); /* :297 */
+    }
+  }
+  for (uint32_t q = 0; q < st.n; ++q) ops_out[q] = st.ops[q];
+  *nops = st.n;
+  free(st.ops);
+  return result;
+}
+
 /* ---- threaded batch drivers (fmitest.c:54-91: static contiguous split) ---- */
 
 typedef struct {

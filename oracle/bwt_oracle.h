@@ -110,6 +110,13 @@ void orc_search_reads_one(const orc_fmi *f, const uint8_t *read, int len, int an
  * reach the caller's stack. */
 int orc_dp_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int mode,
                  uint8_t *ops, uint32_t *nops);
+/* align_read_anchored (single_align.c:163-298): the position it returns (0: not
+ * aligned) and the unit CIGAR operations left on the stack, first pushed first
+ * (room for 5 * len + 64).  ORC_ALIGN_UNDEFINED where the reference calls mms on
+ * no bases or fewer (its behaviour is undefined there). */
+#define ORC_ALIGN_UNDEFINED (-2147483647 - 1)
+int orc_align_read_anchored(const orc_fmi *f, const uint8_t *text, const uint8_t *pattern, int len,
+                            int anchor_len, uint8_t *ops_out, uint32_t *nops);
 
 /* batch drivers used for cpu_baseline timing: threads pthreads, each a
  * contiguous slice (fmitest.c:67-91) */

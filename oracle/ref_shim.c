@@ -123,3 +123,20 @@ int ref_dp_align(const char *s1, int len1, const char *s2, int len2, int mode,
   stack_destroy(s);
   return ret;
 }
+
+/* align_read_anchored (single_align.c:163) on a fresh stack, as main() calls
+ * it (single_align.c:479-483); single_align.c is compiled in with its main
+ * renamed. */
+int align_read_anchored(const fm_index *fmi, const char *seq, const char *pattern, int len, int anchor_len,
+                        stack *s);
+int ref_align_read_anchored(const fm_index *fmi, const char *seq, const char *pattern, int len,
+                            int anchor_len, unsigned char *ops, unsigned *nops) {
+  stack *s = stack_make();
+  const int pos = align_read_anchored(fmi, seq, pattern, len, anchor_len, s);
+  unsigned k = 0;
+  for (int e = 0; e < s->size; ++e)
+    for (int c = 0; c < s->counts[e]; ++c) ops[k++] = (unsigned char)s->chars[e];
+  *nops = k;
+  stack_destroy(s);
+  return pos;
+}

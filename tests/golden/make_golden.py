@@ -164,6 +164,21 @@ def main():
         G["dp"].append({"mode": mode, "seed": seed, "count": count, "max1": max1, "max2": max2,
                         "first": [[r, o.decode()] for r, o in res[:12]], "sha256": dp_digest(res)})
 
+    # 7. align_read_anchored (single_align.c:163-298) with anchor length 12, as single_align.c:483 calls it
+    from helpers import align_cases, align_digest
+    from bwt_amd import synth
+    n = 200000
+    text = orc.gen_genome(n, GENOME_SEED + 7)
+    f = ref.make_fmi(text, n)
+    fo = orc.make_fmi(text, n)
+    reads = align_cases(synth.unpack(text, n), n, 2500, 7200)
+    # reads on which the reference's behaviour is undefined (mms on no bases) are left out, as the oracle marks them
+    keep = [i for i, rd in enumerate(reads) if orc.align_read_anchored(fo, text, rd, 12)[0] != orc.ALIGN_UNDEFINED]
+    res = [ref.align_read_anchored(f, text, reads[i], 12) for i in keep]
+    G["align"] = {"n": n, "genome_seed": GENOME_SEED + 7, "reads_seed": 7200, "count": 2500, "anchor": 12,
+                  "kept": len(keep), "aligned": sum(1 for p, _ in res if p),
+                  "first": [[p, o.decode()] for p, o in res[:6]], "sha256": align_digest(res)}
+
     out = os.path.join(ROOT, "tests", "golden", "golden.json")
     with open(out, "w") as fp:
         json.dump(G, fp, indent=1, sort_keys=True)

@@ -80,3 +80,35 @@ def dp_digest(results):
     import hashlib
 
     return hashlib.sha256(";".join(f"{r}:{o.decode()}" for r, o in results).encode()).hexdigest()
+
+
+def align_cases(bases, n, count, seed, lo=30, hi=151):
+    """Reads for align_read_anchored: cut from the text, then up to four edits
+    (substitution, deletion or insertion of one to three bases, N) from base 12
+    on; every tenth read is random.  Returns a list of uint8 arrays."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(count):
+        L = int(rng.integers(lo, hi))
+        j = int(rng.integers(0, n - L))
+        s = list(bases[j:j + L])
+        for _ in range(int(rng.integers(0, 5))):
+            p = int(rng.integers(12, len(s)))
+            w = int(rng.integers(0, 4))
+            if w == 0:
+                s[p] = (s[p] + 1 + int(rng.integers(0, 3))) & 3
+            elif w == 1:
+                del s[p:p + int(rng.integers(1, 4))]
+            elif w == 2:
+                s[p:p] = list(rng.integers(0, 4, int(rng.integers(1, 4))))
+            else:
+                s[p] = 5
+        if it % 10 == 9:
+            s = list(rng.integers(0, 4, L))
+        out.append(np.array(s, np.uint8))
+    return out
+
+
+def align_digest(results):
+    """one hash over (position, operations) of a list of align_read_anchored results"""
+    return hashlib.sha256(";".join(f"{p}:{o.decode()}" for p, o in results).encode()).hexdigest()
