@@ -45,6 +45,7 @@ SIGNATURES = {
     "bwtgpu_mms": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bwtgpu_search_reads": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, vp, vp]),
     "bwtgpu_align_reads": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, u32, vp, vp, vp, vp]),
+    "bwtgpu_align_reads_host": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp]),
     "bwtgpu_dp_align_batch": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, u32, u32, vp, vp, vp, vp]),
     "bwtgpu_mms_host": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp]),
     "bwtgpu_search_reads_host": (C.c_int, [vp, vp, vp, u64, C.c_int, vp]),

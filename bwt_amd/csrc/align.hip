@@ -185,3 +185,47 @@ extern "C" int bwtgpu_align_reads(const bwtgpu_index *ix, const uint8_t *d_text,
   BWT_CHECK_LAUNCH();
   return kOk;
 }
+
+extern "C" int bwtgpu_align_reads_host(const bwtgpu_index *ix, const uint8_t *h_text, const uint8_t *h_reads,
+                                       const uint64_t *h_offsets, uint64_t R, int anchor_len, int32_t *h_pos,
+                                       uint8_t *h_ops, uint32_t *h_nops) {
+  if (!ix || !h_text || !h_reads || !h_offsets || !h_pos || !h_ops || !h_nops)
+    return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_HIP(hipSetDevice(ix->device));
+  const uint64_t total = h_offsets[R];
+  uint64_t longest = 0;
+  for (uint64_t r = 0; r < R; ++r) {
+    if (h_offsets[r + 1] < h_offsets[r]) return set_error(kErrArg, "read offsets must not decrease");
+    const uint64_t len = h_offsets[r + 1] - h_offsets[r];
+    longest = len > longest ? len : longest;
+  }
+  if (longest > 65535u) return set_error(kErrArg, "reads of up to 65535 bases");
+  const size_t text_bytes = (size_t)ix->n / 4 + 1, ops_bytes = 5 * total + 64 * R;
+  void *d_text = nullptr, *d_reads = nullptr, *d_off = nullptr, *d_pos = nullptr, *d_ops = nullptr, *d_nops = nullptr;
+  hipError_t e = hipMalloc(&d_text, text_bytes + 16);
+  if (e == hipSuccess) e = hipMalloc(&d_reads, total + 16);
+  if (e == hipSuccess) e = hipMalloc(&d_off, (R + 1) * 8);
+  if (e == hipSuccess) e = hipMalloc(&d_pos, R * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_nops, R * 4);
+  if (e == hipSuccess) e = hipMalloc(&d_ops, ops_bytes + 16);
+  int rc = kOk;
+  if (e == hipSuccess) e = hipMemcpy(d_text, h_text, text_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_reads, h_reads, total, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_off, h_offsets, (R + 1) * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    rc = bwtgpu_align_reads(ix, (const uint8_t *)d_text, (const uint8_t *)d_reads, (const uint64_t *)d_off, R,
+                            anchor_len, (uint32_t)longest, (int32_t *)d_pos, (uint8_t *)d_ops, (uint32_t *)d_nops,
+                            nullptr);
+  if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_pos, d_pos, R * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_nops, d_nops, R * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_ops, d_ops, ops_bytes, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) rc = set_error(kErrHip, "align_reads buffers: %s", hipGetErrorString(e));
+  if (d_text) (void)hipFree(d_text);
+  if (d_reads) (void)hipFree(d_reads);
+  if (d_off) (void)hipFree(d_off);
+  if (d_pos) (void)hipFree(d_pos);
+  if (d_nops) (void)hipFree(d_nops);
+  if (d_ops) (void)hipFree(d_ops);
+  return rc;
+}

@@ -494,6 +494,19 @@ int fmi_search_reads_batch(const fm_index *fmi, const char *reads, const unsigne
   return 0;
 }
 
+int fmi_align_reads_batch(const fm_index *fmi, const char *seq, const char *reads,
+                          const unsigned long *offsets, long nreads, int anchor_len, int *pos,
+                          char *ops, unsigned *nops) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_align_reads_host(ix, (const uint8_t *)seq, (const uint8_t *)reads, (const uint64_t *)offsets,
+                              (uint64_t)nreads, anchor_len, pos, (uint8_t *)ops, nops)) {
+    report("align_reads");
+    return -1;
+  }
+  return 0;
+}
+
 void fmi_encode_read(const char *ascii, long len, char *out) {
   /* single_align.c:450-474 */
   for (long i = 0; i < len; ++i) {

@@ -263,6 +263,12 @@ int bwtgpu_mms_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, u
 /* reverses the reads itself */
 int bwtgpu_search_reads_host(const bwtgpu_index *ix, const uint8_t *h_reads,
                              const uint64_t *h_offsets, uint64_t R, int anchor, uint32_t *h_out);
+/* bwtgpu_align_reads with everything on the host: h_text is the packed text
+ * (n/4+1 bytes), h_ops has room for 5 * h_offsets[R] + 64 * R bytes (read r's
+ * operations at 5 * h_offsets[r] + 64 * r). */
+int bwtgpu_align_reads_host(const bwtgpu_index *ix, const uint8_t *h_text, const uint8_t *h_reads,
+                            const uint64_t *h_offsets, uint64_t R, int anchor_len, int32_t *h_pos,
+                            uint8_t *h_ops, uint32_t *h_nops);
 
 /* ---- seeded synthetic inputs, generated in HBM (bench/test plumbing) ---- */
 /* Bit-identical to the host generators in bwt_amd/synth.py. */

@@ -100,6 +100,17 @@ int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, l
  * anchors, last forward position, last backward position (-1: none). */
 int fmi_search_reads_batch(const fm_index *fmi, const char *reads, const unsigned long *offsets,
                            long nreads, int anchor, int *out);
+/* align_read_anchored (single_align.c:163-298) for many reads at once: seq is
+ * the packed sequence the index was built from, reads are stored as for
+ * fmi_search_reads_batch.  pos[r] = the function's return value (0: not
+ * aligned; INT_MIN where the reference calls mms on no bases, which is
+ * undefined there).  The CIGAR stack comes back as unit operations 'M', 'I',
+ * 'D', first pushed first (stack_print_destroy prints from the other end):
+ * nops[r] of them at ops + 5 * offsets[r] + 64 * r; ops holds
+ * 5 * offsets[nreads] + 64 * nreads bytes. */
+int fmi_align_reads_batch(const fm_index *fmi, const char *seq, const char *reads,
+                          const unsigned long *offsets, long nreads, int anchor_len, int *pos,
+                          char *ops, unsigned *nops);
 /* read_index (fileio.c:24) ignores the sequence it is given.  This call hands
  * the packed sequence the index was built from to the device, which checks it
  * against the index and then uses it to speed up searches and locate (same

@@ -179,6 +179,24 @@ def main():
                   "kept": len(keep), "aligned": sum(1 for p, _ in res if p),
                   "first": [[p, o.decode()] for p, o in res[:6]], "sha256": align_digest(res)}
 
+    # 8. the single_align program itself: main() of single_align.c (compiled into _ref under another
+    # name) run in a child process on files made here; its stdout and stderr are what is kept
+    import subprocess
+    from helpers import single_align_inputs
+    with tempfile.TemporaryDirectory() as d:
+        n, text, seq, rds, reads = single_align_inputs(orc, d)
+        idx = os.path.join(d, "genome.idx")
+        assert ref.write_index(ref.make_fmi(text, n), idx) == 0
+        lib = os.path.join(ROOT, "oracle", "_ref", "libbwtref.so")
+        code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); "
+                "a = (ctypes.c_char_p * 4)(*[x.encode() for x in ['single_align'] + sys.argv[2:5]]); "
+                "L.single_align_main(4, a); ctypes.CDLL(None).fflush(None)")
+        run = subprocess.run([sys.executable, "-c", code, lib, seq, idx, rds], capture_output=True, timeout=600)
+        assert run.returncode == 0, run.stderr
+    G["single_align"] = {"reads": len(reads), "stdout_sha256": hashlib.sha256(run.stdout).hexdigest(),
+                         "stdout_lines": run.stdout.count(b"\n"), "stdout_head": run.stdout[:300].decode(),
+                         "stderr": run.stderr.decode()}
+
     out = os.path.join(ROOT, "tests", "golden", "golden.json")
     with open(out, "w") as fp:
         json.dump(G, fp, indent=1, sort_keys=True)

@@ -112,3 +112,35 @@ def align_cases(bases, n, count, seed, lo=30, hi=151):
 def align_digest(results):
     """one hash over (position, operations) of a list of align_read_anchored results"""
     return hashlib.sha256(";".join(f"{p}:{o.decode()}" for p, o in results).encode()).hexdigest()
+
+
+def single_align_inputs(oracle, directory):
+    """The files of the single_align program test: a 120,000-base genome as ASCII,
+    and 1,500 reads (align_cases) one per line; reads on which the reference's
+    align_read_anchored is undefined (it calls mms on no bases), forward or as the
+    reverse complement it tries next, are left out.  Returns (n, packed text,
+    seq path, reads path, the reads as uint8 arrays)."""
+    from bwt_amd import synth
+
+    n = 120000
+    text = oracle.gen_genome(n, GENOME_SEED + 8)
+    bases = synth.unpack(text, n)
+    fo = oracle.make_fmi(text, n)
+    reads = []
+    for rd in align_cases(bases, n, 1500, 7300, lo=30, hi=140):
+        a = oracle.align_read_anchored(fo, text, rd, 12)
+        if a[0] == oracle.ALIGN_UNDEFINED:
+            continue
+        if a[0] == 0:
+            rc = np.where(rd[::-1] == 5, 5, 3 - rd[::-1]).astype(np.uint8)
+            if oracle.align_read_anchored(fo, text, rc, 12)[0] == oracle.ALIGN_UNDEFINED:
+                continue
+        reads.append(rd)
+    seq = os.path.join(directory, "genome.txt")
+    rds = os.path.join(directory, "reads.txt")
+    with open(seq, "w") as fp:
+        fp.write("".join("ACGT"[b] for b in bases))
+    with open(rds, "w") as fp:
+        for rd in reads:
+            fp.write("".join("ACGTNN"[b] for b in rd) + "\n")
+    return n, text, seq, rds, reads

@@ -96,3 +96,28 @@ def test_gpu_align_marks_reads_it_was_not_sized_for(oracle, gpu):
     got = _gpu_align(gpu, gpu.build_index(text, n), text, reads, 12, 100)
     assert got[0] == (0, None)
     assert got[1][0] == 300 and got[1][1] == b"M" * 40
+
+
+@pytest.mark.gpu
+def test_single_align_program_prints_what_the_reference_program_printed(oracle, gpu, tmp_path):
+    """drivers/single_align on the files the reference's own main() was run on
+    when the fixtures were made (tests/golden/make_golden.py): same stdout, same
+    count on stderr."""
+    import hashlib
+    import os
+    import subprocess
+
+    from helpers import ROOT, single_align_inputs
+
+    rec = GOLDEN["single_align"]
+    n, text, seq, rds, reads = single_align_inputs(oracle, str(tmp_path))
+    assert len(reads) == rec["reads"]
+    idx = str(tmp_path / "genome.idx")
+    drv = os.path.join(ROOT, "bwt_amd", "drivers")
+    assert subprocess.run([os.path.join(drv, "build_index"), seq, idx], capture_output=True, timeout=120).returncode == 0
+    run = subprocess.run([os.path.join(drv, "single_align"), seq, idx, rds], capture_output=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    assert run.stdout[:300].decode() == rec["stdout_head"]
+    assert run.stdout.count(b"\n") == rec["stdout_lines"]
+    assert hashlib.sha256(run.stdout).hexdigest() == rec["stdout_sha256"]
+    assert run.stderr.decode().splitlines()[-1] + "\n" == rec["stderr"]
