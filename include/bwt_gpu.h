@@ -201,8 +201,8 @@ int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads,
  * stack_push calls reach the caller's stack (merging runs is stack_push's own
  * rule, stack.c:62-66): d_nops[r] of them at d_ops + d_off1[r] + d_off2[r].
  * No piece may be longer than max_len1 / max_len2, which size the launch (a
- * longer one gets d_nops[r] = 0xFFFFFFFF); 64 KiB of LDS bound them, e.g. 250 x
- * 260 bases. */
+ * longer one gets d_nops[r] = 0xFFFFFFFF); 64 KiB of LDS bound them (470 x 480
+ * bases still fit). */
 int bwtgpu_dp_align_batch(const uint8_t *d_s1, const uint64_t *d_off1, const uint8_t *d_s2,
                           const uint64_t *d_off2, uint64_t R, int mode, uint32_t max_len1,
                           uint32_t max_len2, int32_t *d_ret, uint8_t *d_ops, uint32_t *d_nops,
@@ -212,7 +212,7 @@ int bwtgpu_dp_align_batch(const uint8_t *d_s1, const uint64_t *d_off1, const uin
  * nine bases, nw_fast on the read's tail and head, sw_fast between anchors.
  * d_text is the packed text the index was built from (the reference's `seq`
  * argument); read r is the encoded bytes d_reads[d_offsets[r] .. d_offsets[r+1])
- * (0..3, 5 = N; single_align.c:450-474), none longer than max_len (about 380
+ * (0..3, 5 = N; single_align.c:450-474), none longer than max_len (up to 479
  * bases fit the 64 KiB of LDS).  d_pos[r] = the function's return value (0:
  * not aligned; single_align.c:484-486 prints it + 1).  The CIGAR stack is
  * returned as unit operations 'M', 'I', 'D', first pushed first
