@@ -75,14 +75,14 @@ def test_gpu_align_equals_the_oracle_and_the_golden_vectors(oracle, gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,lo,hi,anchor", [(5000, 25, 60, 12), (300000, 40, 251, 12), (300000, 60, 130, 20),
-                                            (60000, 20, 90, 8)])
+                                            (60000, 20, 90, 8), (300000, 300, 480, 12)])
 def test_gpu_align_more_texts_and_lengths(oracle, gpu, n, lo, hi, anchor):
     text = oracle.gen_genome(n, 31 + n)
     fo = oracle.make_fmi(text, n)
-    reads = align_cases(synth.unpack(text, n), n, 1500, n + anchor, lo=lo, hi=hi)
+    reads = align_cases(synth.unpack(text, n), n, 1500 if hi < 300 else 300, n + anchor, lo=lo, hi=hi)
     reads += [np.array([0, 1, 2], np.uint8), np.zeros(anchor, np.uint8), np.full(40, 5, np.uint8)[:0]]  # short, empty
     want = [oracle.align_read_anchored(fo, text, rd, anchor) if len(rd) else (0, b"") for rd in reads]
-    got = _gpu_align(gpu, gpu.build_index(text, n), text, reads, anchor, hi + 10)
+    got = _gpu_align(gpu, gpu.build_index(text, n), text, reads, anchor, min(hi + 10, 479))
     for rd, g, w in zip(reads, got, want):
         assert g == w, len(rd)
 
