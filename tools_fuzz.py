@@ -150,6 +150,33 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 _lib.check(_lib.load().bwtgpu_search_reads(ix.h, d_f.data_ptr(), d_r.data_ptr(), d_o.data_ptr(),
                                                            len(enc), anchor, out.data_ptr(), None))
                 assert np.array_equal(G.to_numpy_u32(out).reshape(-1, 4), want), f"search_reads {name} anchor={anchor}"
+            # align_read_anchored (single_align.c:163-298), reads of 25..150 bases with edits and N; on
+            # repetitive texts it walks every row of large intervals (as the reference does), so those stay small
+            if n > 400 and (kind in (0, 4) or n <= 4000):
+                al = []
+                for _ in range(80):
+                    L = int(rng.integers(25, min(150, n // 2)))
+                    j = int(rng.integers(0, n - L)); e = list(bases[j:j + L])
+                    for _ in range(int(rng.integers(0, 5))):
+                        q = int(rng.integers(12, len(e))); w = int(rng.integers(0, 4))
+                        if w == 0: e[q] = (e[q] + 1 + int(rng.integers(0, 3))) & 3
+                        elif w == 1: del e[q:q + int(rng.integers(1, 4))]
+                        elif w == 2: e[q:q] = list(rng.integers(0, 4, int(rng.integers(1, 4))))
+                        else: e[q] = 5
+                    if rng.integers(0, 8) == 0: e = list(rng.integers(0, 4, L))
+                    al.append(np.array(e, np.uint8))
+                a_len = int(rng.choice([8, 12, 16, 20]))
+                want = [orc.align_read_anchored(fo, text, e, a_len) for e in al]
+                offs = np.zeros(len(al) + 1, np.int64); offs[1:] = np.cumsum([len(e) for e in al])
+                d_al = torch.from_numpy(np.concatenate(al + [np.zeros(1, np.uint8)])).cuda()
+                d_ao = torch.from_numpy(offs).cuda()
+                for name, ix in (("full", full), ("lean", lean)):
+                    pos, ops, nops = G.align_reads(ix, t, d_al, d_ao, len(al), a_len, 160)
+                    pos_h, ops_h, nops_h = pos.cpu().numpy(), ops.cpu().numpy(), G.to_numpy_u32(nops)
+                    for r in range(len(al)):
+                        o = 5 * int(offs[r]) + 64 * r
+                        got = (int(pos_h[r]), ops_h[o:o + int(nops_h[r])].tobytes())
+                        assert got == want[r], f"align {name} anchor={a_len} read {r} len {len(al[r])}: {got[0]} vs {want[r][0]}"
             full.close(); lean.close()
         except AssertionError as e:
             raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')}: {e}") from e
