@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage (GPU box): tools_asan_driver.sh  -> single_align and search_reads drivers built with host AddressSanitizer,
-# run on the files of the program test
+# run on the files of the program test; the reference-API layer (host/fmi_host.c) is compiled in, instrumented too
 set -u
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/asan; mkdir -p $OUT
 for d in single_align search_reads build_index; do
-  gcc -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=gnu11 -Iinclude -o $OUT/$d bwt_amd/drivers/$d.c \
+  gcc -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=gnu11 -Iinclude -o $OUT/$d bwt_amd/drivers/$d.c bwt_amd/host/fmi_host.c \
       -Lbwt_amd -lbwt_mi355x -Wl,-rpath,$GRAFT_REPO_ROOT/bwt_amd -lpthread || exit 1
 done
 python3 - <<'PY' || exit 1
