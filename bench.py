@@ -41,6 +41,51 @@ def rank_only_bytes_per_read(m, locate_steps=None):
     return b
 
 
+def time_callers(ix, d_text, n, R=1_000_000, m=100):
+    """Kernel rates of the functions that call the search path (seqindex.c:314-351 mms,
+    search_reads.c:115-153, single_align.c:163-298) on one batch of edited reads."""
+    lib = G._lib.load()
+    reads, _ = G.gen_reads(d_text, n, R, m, synth.READS_SEED + 99, want_offsets=False)
+    r = reads[: R * m].view(R, m).clone()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    rows = torch.nonzero(torch.rand(R, generator=g, device="cuda") < 0.3).squeeze(1)
+    for _ in range(2):
+        p = torch.randint(12, m, (R,), generator=g, device="cuda")
+        r[rows, p[rows]] = (r[rows, p[rows]] + 1) & 3
+    rows = torch.nonzero(torch.rand(R, generator=g, device="cuda") < 0.05).squeeze(1)
+    r[rows, torch.randint(12, m, (R,), generator=g, device="cuda")[rows]] = 5
+    flat = torch.cat([r.reshape(-1), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    rev = torch.cat([torch.flip(r, dims=[1]).reshape(-1), torch.zeros(64, dtype=torch.uint8, device="cuda")])
+    offs = torch.arange(R + 1, dtype=torch.int64, device="cuda") * m
+    out = {"reads": R, "read_len": m, "what": "kernel time of one batch, HIP events"}
+
+    def timed(name, fn):
+        for _ in range(2):
+            G.timing_enable(True)
+            G.timing_reset()
+            fn()
+            torch.cuda.synchronize()
+        ms = G.timing_report()[name][1]
+        return {"value": R / (ms * 1e-3), "unit": "reads/s", "kernel_ms": ms}
+
+    got, sp, ep = (torch.empty(R, dtype=torch.int32, device="cuda") for _ in range(3))
+    out["mms"] = timed("fm_mms", lambda: G._lib.check(lib.bwtgpu_mms(
+        ix.h, flat.data_ptr(), m, m, R, got.data_ptr(), sp.data_ptr(), ep.data_ptr(), None)))
+    res = torch.empty(R * 4, dtype=torch.int32, device="cuda")
+    out["search_reads"] = timed("fm_search_reads", lambda: G._lib.check(lib.bwtgpu_search_reads(
+        ix.h, flat.data_ptr(), rev.data_ptr(), offs.data_ptr(), R, 20, res.data_ptr(), None)))
+    out["search_reads"]["anchored_forward"] = int((res.view(R, 4)[:, 0] > 0).sum())
+    if n <= 0x7FFFFFFF:  # the aligner returns positions as int
+        holder = {}
+
+        def run_align():
+            holder["r"] = G.align_reads(ix, d_text, flat, offs, R, 12, m)
+        out["align_reads"] = timed("align_reads", run_align)
+        out["align_reads"]["aligned"] = int((holder["r"][0] != 0).sum())
+    return out
+
+
 def measured_traffic(workload_key):
     """HBM bytes per fm_search launch from the committed PMC passes of this
     workload (profiles/pmc_fm_search.json), or None."""
@@ -103,6 +148,7 @@ def main():
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-callers", action="store_true", help="skip the mms / search_reads / align figures")
     ap.add_argument("--sharded-timeout", type=float, default=240.0,
                     help="seconds the multi-rank sharded build may take before it is reported as stuck")
     ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
@@ -284,6 +330,16 @@ def main():
     achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
     index_bytes = ix.device_bytes
 
+    # ---- the callers of the search path, beside the headline: mms, the search_reads anchor loop,
+    # align_read_anchored; 10^6 reads of 100 bases, 30 % with two substitutions, 5 % with an N ----
+    callers = None
+    if world == 1 and not args.no_callers:
+        try:
+            callers = time_callers(ix, d_text, n)
+        except Exception as e:  # noqa: BLE001 - the headline does not depend on these
+            callers = {"error": f"{type(e).__name__}: {e}"[:300]}
+    G.timing_enable(False)
+
     # ---- the same batch on rank blocks alone (what an index loaded from a file has) ----
     ix.compact()
     sp2, ep2, lr2 = (torch.empty_like(sp) for _ in range(3))
@@ -385,6 +441,7 @@ def main():
             "achieved_gbs": 12.0 * located / (loc_ms * 1e-3) / 1e9 if loc_ms else 0.0,
         },
         "sa_build_sharded": sharded,
+        "callers": callers,
         "search_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(search_kernels.items())},
         "index_bytes": index_bytes,
     }
