@@ -82,7 +82,7 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
     nmisses = 0;
     while (len > anchor_len && anchmisses > 0) {  // :175-206
       uint32_t sp, ep;
-      const int seglen = mms_dev(v, C, pat, 1, len, &sp, &ep, 0);
+      const int seglen = mms_dev<true>(v, C, pat, 1, len, &sp, &ep, 0);
       if (seglen < anchor_len || (int64_t)ep - (int64_t)sp > 1) {
         anchmisses--;
         len -= 3;
@@ -107,7 +107,7 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
           break;
         }
         uint32_t start, end;
-        const int seglen = mms_dev(v, C, pat, 1, len - curgap, &start, &end, 0);
+        const int seglen = mms_dev<true>(v, C, pat, 1, len - curgap, &start, &end, 0);
         bool matched = false;
         for (uint32_t i = start; i < end; ++i) {
           const int64_t here = align_unc_sa(v, i);

@@ -66,6 +66,11 @@ __device__ __forceinline__ uint32_t text_base2(const IndexView &v, uint32_t p) {
 // anchor test of search_reads); when the table shows that the last k bases do
 // not occur and k <= at_least, the answer is "no" without a single rank query
 // and 0 is returned.  0 asks for the exact value.
+//
+// WAVE: the 64 lanes of the calling wave run the call together on one pattern
+// (the aligner); the comparison with the text then takes 64 bases a step, one
+// per lane, instead of one.
+template <bool WAVE = false>
 __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const uint8_t *pat, int step,
                                        int len, uint32_t *sp_out, uint32_t *ep_out, int at_least,
                                        int hint = 0, uint32_t hx = 0) {
@@ -118,10 +123,28 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     if (v.sa && end - start == 1) {
       const uint32_t pos = v.sa[start];
       uint32_t k = 0;  // bases that agree with the text in front of pos
-      while ((int)k <= i && k < pos) {
-        const uint32_t raw = pat[(i - (int)k) * step];
-        if (raw != 5 && (raw & 3u) != text_base2(v, pos - 1 - k)) break;
-        ++k;
+      if (WAVE) {
+        const uint32_t lane = threadIdx.x & 63u;
+        for (;;) {
+          const uint32_t kk = k + lane;
+          bool agrees = false;
+          if ((int)kk <= i && kk < pos) {
+            const uint32_t raw = pat[(i - (int)kk) * step];
+            agrees = raw == 5 || (raw & 3u) == text_base2(v, pos - 1 - kk);
+          }
+          const uint64_t stops = __ballot(!agrees);  // the first lane that disagrees or is past the end
+          if (stops) {
+            k += (uint32_t)__ffsll((unsigned long long)stops) - 1u;
+            break;
+          }
+          k += 64;
+        }
+      } else {
+        while ((int)k <= i && k < pos) {
+          const uint32_t raw = pat[(i - (int)k) * step];
+          if (raw != 5 && (raw & 3u) != text_base2(v, pos - 1 - k)) break;
+          ++k;
+        }
       }
       const uint32_t row = k ? isa_at(v, pos - k) : start;
       *sp_out = row;
