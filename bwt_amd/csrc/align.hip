@@ -109,11 +109,22 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
         uint32_t start, end;
         const int seglen = mms_dev<true>(v, C, pat, 1, len - curgap, &start, &end, 0);
         bool matched = false;
-        for (uint32_t i = start; i < end; ++i) {
-          const int64_t here = align_unc_sa(v, i);
-          int64_t dist = here + seglen - curpos;
-          if (dist < 0) dist = -dist;
-          if (dist - curgap <= 3) {
+        // the rows of the interval in order, 64 at a time, one per lane; the first
+        // that lies within 3 + curgap of the anchor is taken (:217-218)
+        for (uint64_t first = start; first < end && !matched; first += 64) {
+          const uint64_t i = first + lane;
+          int here32 = 0;
+          bool near = false;
+          if (i < end) {
+            const int64_t h = align_unc_sa(v, (uint32_t)i);
+            int64_t dist = h + seglen - curpos;
+            if (dist < 0) dist = -dist;
+            near = dist - curgap <= 3;
+            here32 = (int)h;  // texts of up to 2^31 - 1 bases
+          }
+          const uint64_t hits = __ballot(near);
+          if (hits) {
+            const int64_t here = __shfl(here32, __ffsll((unsigned long long)hits) - 1, 64);
             nmisses -= curgap;
             matched = true;
             const int64_t buflen = curpos - (here + seglen);
@@ -123,7 +134,6 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
             curpos = here;
             len -= seglen + curgap;
             curgap = 0;
-            break;
           }
         }
         if (matched) break;

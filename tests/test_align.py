@@ -121,3 +121,20 @@ def test_single_align_program_prints_what_the_reference_program_printed(oracle, 
     assert run.stdout.count(b"\n") == rec["stdout_lines"]
     assert hashlib.sha256(run.stdout).hexdigest() == rec["stdout_sha256"]
     assert run.stderr.decode().splitlines()[-1] + "\n" == rec["stderr"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period,mutations", [(7, 0), (50, 0), (50, 60)])
+def test_gpu_align_on_repeats(oracle, gpu, period, mutations):
+    """Tandem repeats: anchors are rarely unique and the gap search walks
+    intervals of hundreds of rows (single_align.c:217-218), 64 rows a step on
+    the GPU, taking the first that fits as the reference does."""
+    n = 4000
+    text = synth.gen_tandem(n, period, 5, mutations, 9 if mutations else 0)
+    fo = oracle.make_fmi(text, n)
+    reads = align_cases(synth.unpack(text, n), n, 300, 1234 + period, lo=30, hi=120)
+    want = [oracle.align_read_anchored(fo, text, rd, 12) for rd in reads]
+    for ix in (gpu.build_index(text, n), gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)):
+        got = _gpu_align(gpu, ix, text, reads, 12, 130)
+        for rd, g, w in zip(reads, got, want):
+            assert g == w, len(rd)
