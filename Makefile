@@ -35,8 +35,8 @@ drivers: $(DRIVERS)
 $(DRV)/%: $(DRV)/%.c $(LIB) $(wildcard include/*.h)
 	$(CC) $(CFLAGS) -o $@ $< -Lbwt_amd -lbwt_mi355x -Wl,-rpath,'$$ORIGIN/..' -lpthread
 
-oracle:
-	$(MAKE) -C oracle all
+oracle: $(LIB)
+	$(MAKE) -C oracle all refprogs
 
 clean:
 	rm -f $(HIP_OBJS) $(HOST_OBJS) $(LIB) $(DRIVERS)

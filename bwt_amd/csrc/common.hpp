@@ -30,6 +30,25 @@ int set_error(int code, const char *fmt, ...);
 // runtime.hip: device buffers that are reused across indexes (exact-size
 // matches); pool_release_idle() returns the idle ones to the driver.
 hipError_t pool_alloc(void **out, size_t bytes);
+
+// Small calls through the host-buffer entry points (a batch of one is what the
+// reference's scalar functions become) skip the copies: the calling thread
+// keeps 64 KiB of pinned host memory that the device reads and writes in
+// place, so a call is a memcpy into it, the launches and one synchronisation.
+struct Mailbox {
+  static constexpr size_t kBytes = 64 * 1024;
+  uint8_t *host = nullptr, *dev = nullptr;  // the same memory, as the host and as the device address it
+  void *ws = nullptr;                        // device scratch kept beside it, grown on demand
+  size_t ws_bytes = 0;
+  int device = -1;
+  bool open(int device_ordinal);             // false: no pinned memory to be had, take the copying path
+  bool scratch(size_t bytes);
+  template <class T> T *on_device(const void *host_ptr) const {
+    return reinterpret_cast<T *>(dev + (static_cast<const uint8_t *>(host_ptr) - host));
+  }
+  ~Mailbox();
+};
+Mailbox &thread_mailbox();
 void pool_free(void *p);
 void pool_release_idle();
 template <class T>

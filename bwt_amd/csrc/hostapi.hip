@@ -1,6 +1,8 @@
 // Host-pointer forms of the device entry points: upload, run the same kernels,
 // download.  These are what the C host layer (bwt_amd/host) calls to stand in
 // for the reference's host functions; the compute is still all on the GPU.
+#include <cstring>
+
 #include "common.hpp"
 #include "fm_device.hpp"
 
@@ -21,6 +23,12 @@ struct Dev {
   hipError_t alloc(size_t bytes) { return pool_alloc(&p, bytes ? bytes : 256); }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
+
+// Layout of a small call in the thread's mailbox (see Mailbox): inputs first,
+// then up to kBoxReads results of each kind.
+constexpr uint64_t kBoxReads = 256;
+constexpr size_t kBoxInput = 32 * 1024;
+constexpr size_t kBoxOut = kBoxInput + 256;  // four arrays of kBoxReads words follow
 
 // Occ(c, idx) on the packed BWT (no C, no $ adjustment): seq_rank, seqindex.c:91-111
 __global__ void k_occ_batch(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
@@ -126,6 +134,28 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
   if (!ix || !h_pats || m == 0) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
+  {
+    // a few reads (the reference's scalar calls are batches of one): through the mailbox, no copies
+    Mailbox &box = thread_mailbox();
+    const uint64_t bytes = (R - 1) * stride + m;
+    const size_t wsb = bwtgpu_search_workspace_bytes(R, m), lwsb = bwtgpu_locate_workspace_bytes();
+    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) && box.scratch(wsb + 256 + lwsb)) {
+      memcpy(box.host, h_pats, bytes);
+      uint32_t *out = reinterpret_cast<uint32_t *>(box.host + kBoxOut);
+      uint32_t *d_out = box.on_device<uint32_t>(out);
+      uint8_t *lws = static_cast<uint8_t *>(box.ws) + align_up(wsb, 256);
+      BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads,
+                            (h_pos || h_locrow) ? d_out + 2 * kBoxReads : nullptr, box.ws, wsb, nullptr));
+      if (h_pos)
+        BWT_TRY(bwtgpu_locate_rows(ix, d_out + 2 * kBoxReads, R, d_out + 3 * kBoxReads, nullptr, lws, lwsb, nullptr));
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      if (h_sp) memcpy(h_sp, out, R * 4);
+      if (h_ep) memcpy(h_ep, out + kBoxReads, R * 4);
+      if (h_locrow) memcpy(h_locrow, out + 2 * kBoxReads, R * 4);
+      if (h_pos) memcpy(h_pos, out + 3 * kBoxReads, R * 4);
+      return kOk;
+    }
+  }
   const uint64_t chunk_max = stride ? (1ull << 30) / (stride > m ? stride : m) + 1 : R;
   const uint64_t chunk = R < chunk_max ? R : chunk_max;
   Dev pats, sp, ep, lr, pos, ws, lws;
@@ -160,6 +190,24 @@ int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, ui
   if (!ix || !h_pats || !h_result || m == 0) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
+  {
+    Mailbox &box = thread_mailbox();
+    const uint64_t bytes = (R - 1) * stride + m;
+    const size_t wsb = bwtgpu_search_workspace_bytes(R, m);
+    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) && box.scratch(wsb)) {
+      memcpy(box.host, h_pats, bytes);
+      uint32_t *out = reinterpret_cast<uint32_t *>(box.host + kBoxOut);
+      uint32_t *d_out = box.on_device<uint32_t>(out);
+      BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads, box.ws,
+                            wsb, nullptr));
+      BWT_LAUNCH("reverse_result", k_reverse_result, dim3(1), dim3(256), 0, nullptr, d_out, d_out + kBoxReads,
+                 d_out + 2 * kBoxReads, R);
+      BWT_CHECK_LAUNCH();
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      memcpy(h_result, out, R * 4);
+      return kOk;
+    }
+  }
   const uint64_t chunk_max = stride ? (1ull << 30) / (stride > m ? stride : m) + 1 : R;
   const uint64_t chunk = R < chunk_max ? R : chunk_max;
   Dev pats, sp, ep, lr, ws;
@@ -188,6 +236,19 @@ int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint
   if (!ix || !h_rows || !h_pos) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
+  {
+    Mailbox &box = thread_mailbox();
+    const size_t lwsb = bwtgpu_locate_workspace_bytes();
+    if (R <= kBoxReads && box.open(ix->device) && box.scratch(lwsb)) {
+      uint32_t *io = reinterpret_cast<uint32_t *>(box.host);
+      memcpy(io, h_rows, R * 4);
+      BWT_TRY(bwtgpu_locate_rows(ix, box.on_device<uint32_t>(io), R, box.on_device<uint32_t>(io + kBoxReads),
+                                 nullptr, box.ws, lwsb, nullptr));
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      memcpy(h_pos, io + kBoxReads, R * 4);
+      return kOk;
+    }
+  }
   Dev rows, pos, lws;
   hipError_t e = rows.alloc(R * 4);
   if (e == hipSuccess) e = pos.alloc(R * 4);
@@ -205,6 +266,20 @@ int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *
   if (!ix || !h_c || !h_idx || !h_out) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
+  {
+    Mailbox &box = thread_mailbox();
+    if (R <= kBoxReads && box.open(ix->device)) {
+      uint32_t *io = reinterpret_cast<uint32_t *>(box.host);
+      uint8_t *cs = box.host + 2 * kBoxReads * 4;
+      memcpy(io, h_idx, R * 4);
+      memcpy(cs, h_c, R);
+      BWT_TRY(bwtgpu_occ_batch(ix, box.on_device<uint8_t>(cs), box.on_device<uint32_t>(io), R, skip_dollar_row,
+                               box.on_device<uint32_t>(io + kBoxReads), nullptr));
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      memcpy(h_out, io + kBoxReads, R * 4);
+      return kOk;
+    }
+  }
   Dev c, idx, out;
   hipError_t e = c.alloc(R);
   if (e == hipSuccess) e = idx.alloc(R * 4);
@@ -222,6 +297,17 @@ int bwtgpu_lf_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R, u
   if (!ix || !h_rows || !h_out) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
+  {
+    Mailbox &box = thread_mailbox();
+    if (R <= kBoxReads && box.open(ix->device)) {
+      uint32_t *io = reinterpret_cast<uint32_t *>(box.host);
+      memcpy(io, h_rows, R * 4);
+      BWT_TRY(bwtgpu_lf_batch(ix, box.on_device<uint32_t>(io), R, box.on_device<uint32_t>(io + kBoxReads), nullptr));
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      memcpy(h_out, io + kBoxReads, R * 4);
+      return kOk;
+    }
+  }
   Dev rows, out;
   hipError_t e = rows.alloc(R * 4);
   if (e == hipSuccess) e = out.alloc(R * 4);

@@ -1,5 +1,7 @@
 // Maximum-mappable-suffix search (mms, seqindex.c:314-351) and the anchor loop
 // of search_reads (search_reads.c:102-160), one read per lane.
+#include <cstring>
+
 #include "common.hpp"
 #include "fm_device.hpp"
 #include "mms_device.hpp"
@@ -193,8 +195,24 @@ int bwtgpu_mms_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, u
   if (!ix || !h_pats || !h_matched || !h_sp || !h_ep) return set_error(kErrArg, "null argument");
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
-  void *pats = nullptr, *out = nullptr;
   const size_t pb = (R - 1) * stride + m;
+  {
+    // a few patterns (the reference's mms is a batch of one): through the thread's mailbox, no copies
+    Mailbox &box = thread_mailbox();
+    if (R <= 256 && pb <= 32 * 1024 && box.open(ix->device)) {
+      memcpy(box.host, h_pats, pb);
+      uint32_t *res = reinterpret_cast<uint32_t *>(box.host + 32 * 1024 + 256);
+      uint32_t *d_res = box.on_device<uint32_t>(res);
+      BWT_TRY(bwtgpu_mms(ix, box.dev, m, stride, R, reinterpret_cast<int32_t *>(d_res), d_res + 256, d_res + 512,
+                         nullptr));
+      BWT_HIP(hipStreamSynchronize(nullptr));
+      memcpy(h_matched, res, R * 4);
+      memcpy(h_sp, res + 256, R * 4);
+      memcpy(h_ep, res + 512, R * 4);
+      return kOk;
+    }
+  }
+  void *pats = nullptr, *out = nullptr;
   hipError_t e = hipMalloc(&pats, pb);
   if (e == hipSuccess) e = hipMalloc(&out, R * 12);
   int rc = kOk;

@@ -133,6 +133,52 @@ static void timing_resolve() {
   t.pending.clear();
 }
 
+bool Mailbox::open(int device_ordinal) {
+  if (host && device == device_ordinal) return true;
+  if (host) {
+    (void)hipHostFree(host);
+    if (ws) (void)hipFree(ws);
+    host = dev = nullptr;
+    ws = nullptr;
+    ws_bytes = 0;
+  }
+  void *h = nullptr, *d = nullptr;
+  if (hipHostMalloc(&h, kBytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+      hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    if (h) (void)hipHostFree(h);
+    return false;
+  }
+  host = static_cast<uint8_t *>(h);
+  dev = static_cast<uint8_t *>(d);
+  device = device_ordinal;
+  return true;
+}
+
+bool Mailbox::scratch(size_t bytes) {
+  if (bytes <= ws_bytes) return true;
+  if (ws) (void)hipFree(ws);
+  ws = nullptr;
+  ws_bytes = 0;
+  if (hipMalloc(&ws, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  ws_bytes = bytes;
+  return true;
+}
+
+Mailbox::~Mailbox() {
+  // Runs at thread exit, for the main thread after the HIP runtime may have shut
+  // down: nothing is freed here (64 KiB of pinned memory and the scratch stay
+  // with the process).
+}
+
+Mailbox &thread_mailbox() {
+  static thread_local Mailbox box;
+  return box;
+}
+
 }  // namespace bwtgpu
 
 using namespace bwtgpu;

@@ -62,3 +62,31 @@ def test_host_packer_matches_build_index(oracle):
         out = ctypes.create_string_buffer(len(text) // 4 + 1)
         hl.fmi_pack_ascii(text, ctypes.c_long(len(text)), out)
         assert out.raw == oracle.pack_ascii(text).tobytes()
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree is not on this machine")
+@pytest.mark.parametrize("program,extra", [("build_index", []), ("fmitest", []), ("searchtest", []), ("filetest", []),
+                                           ("index_test", []), ("search_reads", []), ("gaptest", []),
+                                           ("histsortcomptest", []), ("single_align", ["smw.c", "stack.c"]),
+                                           ("rnaseqtest", ["smw.c", "stack.c"])])
+def test_reference_programs_link_against_the_library(program, extra, tmp_path):
+    """The reference's own programs, compiled from where they lie with the
+    reference's own headers, link with libbwt_mi355x.so in place of
+    histsortcomp.o csacak.o seqindex.o fileio.o (reference Makefile:32-60; the
+    aligners keep their own smw.c and stack.c): every symbol they use is
+    exported.  Nothing is run (no device here) and nothing is
+    kept."""
+    import subprocess
+
+    src = os.path.join(REFERENCE, program + ".c")
+    if not os.path.exists(src):
+        pytest.skip(f"{program}.c is not in the reference tree")
+    out = str(tmp_path / program)
+    lib_dir = os.path.join(ROOT, "bwt_amd")
+    res = subprocess.run(["gcc", "-std=gnu99", "-O1", "-w", "-pthread", "-I" + REFERENCE, "-o", out, src]
+                         + [os.path.join(REFERENCE, e) for e in extra] + ["-L" + lib_dir, "-lbwt_mi355x", "-Wl,-rpath," + lib_dir, "-lm"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
