@@ -268,6 +268,27 @@ __global__ void k_locate_sa(IndexView v, const uint32_t *__restrict__ rows, uint
   pos[r] = row > v.n ? 0xFFFFFFFFu : v.sa[row];
 }
 
+// unc_sa (seqindex.c:244-255) for a handful of rows (the reference's scalar
+// calls are batches of one): a row per lane, no queue to set up.
+__global__ void __launch_bounds__(256)
+k_locate_few(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *__restrict__ pos) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  uint32_t idx = rows[r], steps = 0;
+  if (idx > v.n) {
+    pos[r] = 0xFFFFFFFFu;
+    return;
+  }
+  while (idx & kDevSampleMask) {
+    idx = lf_step(v, idx);
+    ++steps;
+  }
+  uint64_t x = (uint64_t)v.idxs[idx >> kDevSampleShift] + steps;
+  if (x > v.n) x -= (uint64_t)v.n + 1;
+  pos[r] = (uint32_t)x;
+}
+
+constexpr uint32_t kLocateFew = 4096;   // up to this many rows skip the queue
 constexpr uint32_t kLocateBatch = 256;  // rows a wave takes from the queue at a time
 constexpr int kLocateSlots = 2;         // independent walks per lane
 
@@ -487,6 +508,12 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
   if (ix->d_sa) {
     BWT_LAUNCH("fm_locate", k_locate_sa, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows,
                R, d_pos);
+    BWT_CHECK_LAUNCH();
+    return kOk;
+  }
+  if (R <= kLocateFew && !d_steps) {
+    BWT_LAUNCH("fm_locate", k_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows, R,
+               d_pos);
     BWT_CHECK_LAUNCH();
     return kOk;
   }
