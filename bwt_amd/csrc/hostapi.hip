@@ -5,6 +5,7 @@
 
 #include "common.hpp"
 #include "fm_device.hpp"
+#include "mms_device.hpp"
 
 namespace bwtgpu {
 
@@ -27,8 +28,39 @@ struct Dev {
 // Layout of a small call in the thread's mailbox (see Mailbox): inputs first,
 // then up to kBoxReads results of each kind.
 constexpr uint64_t kBoxReads = 256;
+constexpr uint32_t kFewMaxLen = 64;  // reads up to this long take the one-launch kernel
 constexpr size_t kBoxInput = 32 * 1024;
 constexpr size_t kBoxOut = kBoxInput + 256;  // four arrays of kBoxReads words follow
+
+// loc_search (seqindex.c:280-309) and, when pos is given, locate's unc_sa
+// (seqindex.c:265-276, 244-255) for a handful of reads in one launch: a read per
+// lane, two rank queries a step, nothing else -- what a scalar call of the
+// reference's API turns into.  Same outputs as bwtgpu_search + bwtgpu_locate_rows.
+__global__ void __launch_bounds__(256)
+k_search_locate_few(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, uint64_t stride,
+                    uint64_t R, uint32_t *__restrict__ sp_out, uint32_t *__restrict__ ep_out,
+                    uint32_t *__restrict__ row_out, uint32_t *__restrict__ pos_out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const uint8_t *p = pats + r * stride;
+  uint32_t c = p[m - 1] & 3u;
+  uint32_t sp = c_of(C, c), ep = c_of(C, c + 1);
+  bool early = false;
+  for (int i = (int)m - 2; i >= 0; --i) {
+    if (ep <= sp) {  // seqindex.c:299-301
+      early = true;
+      break;
+    }
+    c = p[i] & 3u;
+    sp = occ_sym(v, c, sp);
+    ep = occ_sym(v, c, ep);
+  }
+  sp_out[r] = sp;
+  ep_out[r] = ep;
+  const uint32_t row = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
+  row_out[r] = row;
+  if (pos_out) pos_out[r] = row > v.n ? 0xFFFFFFFFu : (v.sa ? v.sa[row] : unc_sa_dev(v, row));
+}
 
 // Occ(c, idx) on the packed BWT (no C, no $ adjustment): seq_rank, seqindex.c:91-111
 __global__ void k_occ_batch(IndexView v, uint32_t C0, uint32_t C1, uint32_t C2, uint32_t C3,
@@ -139,15 +171,27 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
     Mailbox &box = thread_mailbox();
     const uint64_t bytes = (R - 1) * stride + m;
     const size_t wsb = bwtgpu_search_workspace_bytes(R, m), lwsb = bwtgpu_locate_workspace_bytes();
-    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) && box.scratch(wsb + 256 + lwsb)) {
+    const bool one_launch = m <= kFewMaxLen;  // longer reads are worth staging through LDS: the search kernel proper
+    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) &&
+        (one_launch || box.scratch(wsb + 256 + lwsb))) {
       memcpy(box.host, h_pats, bytes);
       uint32_t *out = reinterpret_cast<uint32_t *>(box.host + kBoxOut);
       uint32_t *d_out = box.on_device<uint32_t>(out);
-      uint8_t *lws = static_cast<uint8_t *>(box.ws) + align_up(wsb, 256);
-      BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads,
-                            (h_pos || h_locrow) ? d_out + 2 * kBoxReads : nullptr, box.ws, wsb, nullptr));
-      if (h_pos)
-        BWT_TRY(bwtgpu_locate_rows(ix, d_out + 2 * kBoxReads, R, d_out + 3 * kBoxReads, nullptr, lws, lwsb, nullptr));
+      if (one_launch) {
+        CTab C;
+        for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+        BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, nullptr,
+                   view_of(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
+                   h_pos ? d_out + 3 * kBoxReads : nullptr);
+        BWT_CHECK_LAUNCH();
+      } else {
+        uint8_t *lws = static_cast<uint8_t *>(box.ws) + align_up(wsb, 256);
+        BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads,
+                              (h_pos || h_locrow) ? d_out + 2 * kBoxReads : nullptr, box.ws, wsb, nullptr));
+        if (h_pos)
+          BWT_TRY(bwtgpu_locate_rows(ix, d_out + 2 * kBoxReads, R, d_out + 3 * kBoxReads, nullptr, lws, lwsb,
+                                     nullptr));
+      }
       BWT_HIP(hipStreamSynchronize(nullptr));
       if (h_sp) memcpy(h_sp, out, R * 4);
       if (h_ep) memcpy(h_ep, out + kBoxReads, R * 4);

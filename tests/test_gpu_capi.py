@@ -127,6 +127,15 @@ def test_make_fmi_struct_and_scalar_queries(capi, oracle):
         assert capi.reverse_search(fmi, _p(reads[r]), 20) == oracle.reverse_search(fo, reads[r])
         if ep.value - sp.value == 1:
             assert capi.locate(fmi, _p(reads[r]), 20) == oracle.locate(fo, reads[r])
+    # longer reads take the other small-call path (the search kernel proper), absent and mutated ones included
+    long_reads, _ = oracle.gen_reads(text, n, 30, 150, READS_SEED + 1)
+    long_reads[::3, 75] = (long_reads[::3, 75] + 1) & 3
+    for r in range(30):
+        sp, ep = C.c_int(), C.c_int()
+        capi.loc_search(fmi, _p(long_reads[r]), 150, C.byref(sp), C.byref(ep))
+        assert (sp.value, ep.value) == oracle.loc_search(fo, long_reads[r])
+        assert capi.reverse_search(fmi, _p(long_reads[r]), 150) == oracle.reverse_search(fo, long_reads[r])
+        assert capi.locate(fmi, _p(long_reads[r]), 150) == oracle.locate(fo, long_reads[r])
     # seq_index / seq_rank on a caller-owned BWT
     bwt = fo.bwt.copy()
     tbl = oracle.lookup_table()
