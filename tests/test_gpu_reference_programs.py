@@ -41,3 +41,26 @@ def test_reference_filetest_passes_on_the_library(oracle, gpu, tmp_path):
         assert i > 0 and lines[i - 1].startswith("Warning: multiple matches")
     assert set(ln.split()[0] for ln in lines) <= {"Warning:", "Ruh"}
     print(f"filetest: 10^6 scalar locate calls in {seconds:.1f} s, {warnings} repeated 16-mers, {len(wrong)} of them elsewhere")
+
+
+SINGLE_ALIGN = os.path.join(ROOT, "oracle", "_ref", "single_align_on_mi355x")
+
+
+@pytest.mark.skipif(not os.path.exists(SINGLE_ALIGN), reason="oracle/_ref/single_align_on_mi355x was not built")
+def test_reference_single_align_prints_the_same_on_the_library(oracle, gpu, tmp_path):
+    """The reference's single_align.c with its own smw.c and stack.c, every mms,
+    unc_sa and read_index a call into the MI355X library: the output of the run
+    the fixtures were made from (there on the reference's own objects)."""
+    import hashlib
+
+    from helpers import GOLDEN, single_align_inputs
+
+    rec = GOLDEN["single_align"]
+    n, text, seq, rds, reads = single_align_inputs(oracle, str(tmp_path))
+    idx = str(tmp_path / "genome.idx")
+    drv = os.path.join(ROOT, "bwt_amd", "drivers")
+    assert subprocess.run([os.path.join(drv, "build_index"), seq, idx], capture_output=True, timeout=120).returncode == 0
+    run = subprocess.run([SINGLE_ALIGN, seq, idx, rds], capture_output=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-1000:]
+    assert hashlib.sha256(run.stdout).hexdigest() == rec["stdout_sha256"]
+    assert run.stderr.decode().splitlines()[-1] + "\n" == rec["stderr"]
