@@ -64,3 +64,24 @@ def test_reference_single_align_prints_the_same_on_the_library(oracle, gpu, tmp_
     assert run.returncode == 0, run.stderr[-1000:]
     assert hashlib.sha256(run.stdout).hexdigest() == rec["stdout_sha256"]
     assert run.stderr.decode().splitlines()[-1] + "\n" == rec["stderr"]
+
+
+BUILD_INDEX = os.path.join(ROOT, "oracle", "_ref", "build_index_on_mi355x")
+
+
+@pytest.mark.skipif(not os.path.exists(BUILD_INDEX), reason="oracle/_ref/build_index_on_mi355x was not built")
+def test_reference_build_index_writes_the_same_file_on_the_library(oracle, gpu, tmp_path):
+    """The reference's build_index.c (its packer, make_fmi or make_fmi_sacak, write_index) on the library, and
+    this repository's drivers/build_index: the same index file, byte for byte, which is also the file the
+    oracle writes for that text."""
+    from helpers import single_align_inputs
+
+    n, text, seq, _, _ = single_align_inputs(oracle, str(tmp_path))
+    theirs, ours, want = (str(tmp_path / x) for x in ("ref.idx", "drv.idx", "orc.idx"))
+    assert subprocess.run([BUILD_INDEX, seq, theirs], capture_output=True, timeout=120).returncode == 0
+    drv = os.path.join(ROOT, "bwt_amd", "drivers", "build_index")
+    assert subprocess.run([drv, seq, ours], capture_output=True, timeout=120).returncode == 0
+    assert oracle.write_index(oracle.make_fmi(text, n), want) == 0
+    data = open(theirs, "rb").read()
+    assert data == open(ours, "rb").read()
+    assert data == open(want, "rb").read()
