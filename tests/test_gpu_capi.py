@@ -148,6 +148,35 @@ def test_make_fmi_struct_and_scalar_queries(capi, oracle):
     capi.destroy_fmi(fmi)
 
 
+def test_scalar_queries_from_four_threads(capi, oracle):
+    """fmitest.c:67-91 calls the query functions from four threads without locks:
+    scalar calls from four threads at once (ctypes drops the interpreter lock
+    around each) give what the oracle gives."""
+    import threading
+
+    n = 60000
+    text = oracle.gen_genome(n, GENOME_SEED + 3)
+    fo = oracle.make_fmi(text, n)
+    fmi = capi.make_fmi(_p(text), n)
+    reads, _ = oracle.gen_reads(text, n, 4 * 1500, 14, READS_SEED + 5)
+    want = [(oracle.loc_search(fo, r), oracle.reverse_search(fo, r)) for r in reads]
+    got = [None] * len(reads)
+
+    def work(t):
+        for r in range(t, len(reads), 4):
+            sp, ep = C.c_int(), C.c_int()
+            capi.loc_search(fmi, _p(reads[r]), 14, C.byref(sp), C.byref(ep))
+            got[r] = ((sp.value, ep.value), capi.reverse_search(fmi, _p(reads[r]), 14))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want
+    capi.destroy_fmi(fmi)
+
+
 def test_batch_forms_and_index_file(capi, oracle, tmp_path):
     rec = GOLDEN["random"][4]  # n = 10^6, 10k x 20
     n, R, m = rec["n"], rec["R"], rec["m"]
