@@ -39,6 +39,7 @@ struct Mailbox {
   static constexpr size_t kBytes = 64 * 1024;
   uint8_t *host = nullptr, *dev = nullptr;  // the same memory, as the host and as the device address it
   void *ws = nullptr;                        // device scratch kept beside it, grown on demand
+  hipStream_t stream = nullptr;              // the thread's own: calls from several threads do not wait for each other
   size_t ws_bytes = 0;
   int device = -1;
   bool open(int device_ordinal);             // false: no pinned memory to be had, take the copying path

@@ -180,19 +180,19 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
       if (one_launch) {
         CTab C;
         for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
-        BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, nullptr,
+        BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, box.stream,
                    view_of(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
                    h_pos ? d_out + 3 * kBoxReads : nullptr);
         BWT_CHECK_LAUNCH();
       } else {
         uint8_t *lws = static_cast<uint8_t *>(box.ws) + align_up(wsb, 256);
         BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads,
-                              (h_pos || h_locrow) ? d_out + 2 * kBoxReads : nullptr, box.ws, wsb, nullptr));
+                              (h_pos || h_locrow) ? d_out + 2 * kBoxReads : nullptr, box.ws, wsb, box.stream));
         if (h_pos)
           BWT_TRY(bwtgpu_locate_rows(ix, d_out + 2 * kBoxReads, R, d_out + 3 * kBoxReads, nullptr, lws, lwsb,
-                                     nullptr));
+                                     box.stream));
       }
-      BWT_HIP(hipStreamSynchronize(nullptr));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       if (h_sp) memcpy(h_sp, out, R * 4);
       if (h_ep) memcpy(h_ep, out + kBoxReads, R * 4);
       if (h_locrow) memcpy(h_locrow, out + 2 * kBoxReads, R * 4);
@@ -238,16 +238,29 @@ int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, ui
     Mailbox &box = thread_mailbox();
     const uint64_t bytes = (R - 1) * stride + m;
     const size_t wsb = bwtgpu_search_workspace_bytes(R, m);
-    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) && box.scratch(wsb)) {
+    const bool one_launch = m <= kFewMaxLen;
+    if (R <= kBoxReads && bytes <= kBoxInput && box.open(ix->device) && (one_launch || box.scratch(wsb))) {
       memcpy(box.host, h_pats, bytes);
       uint32_t *out = reinterpret_cast<uint32_t *>(box.host + kBoxOut);
       uint32_t *d_out = box.on_device<uint32_t>(out);
+      if (one_launch) {
+        CTab C;
+        for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+        BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, box.stream,
+                   view_of(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
+                   (uint32_t *)nullptr);
+        BWT_CHECK_LAUNCH();
+        BWT_HIP(hipStreamSynchronize(box.stream));
+        for (uint64_t r = 0; r < R; ++r)  // seqindex.c:228-242: 0 if the interval emptied early, else ep - sp + 1 (sic)
+          h_result[r] = out[2 * kBoxReads + r] == 0xFFFFFFFFu ? 0 : (int32_t)(out[kBoxReads + r] - out[r] + 1u);
+        return kOk;
+      }
       BWT_TRY(bwtgpu_search(ix, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads, box.ws,
-                            wsb, nullptr));
-      BWT_LAUNCH("reverse_result", k_reverse_result, dim3(1), dim3(256), 0, nullptr, d_out, d_out + kBoxReads,
+                            wsb, box.stream));
+      BWT_LAUNCH("reverse_result", k_reverse_result, dim3(1), dim3(256), 0, box.stream, d_out, d_out + kBoxReads,
                  d_out + 2 * kBoxReads, R);
       BWT_CHECK_LAUNCH();
-      BWT_HIP(hipStreamSynchronize(nullptr));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       memcpy(h_result, out, R * 4);
       return kOk;
     }
@@ -287,8 +300,8 @@ int bwtgpu_locate_rows_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint
       uint32_t *io = reinterpret_cast<uint32_t *>(box.host);
       memcpy(io, h_rows, R * 4);
       BWT_TRY(bwtgpu_locate_rows(ix, box.on_device<uint32_t>(io), R, box.on_device<uint32_t>(io + kBoxReads),
-                                 nullptr, box.ws, lwsb, nullptr));
-      BWT_HIP(hipStreamSynchronize(nullptr));
+                                 nullptr, box.ws, lwsb, box.stream));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       memcpy(h_pos, io + kBoxReads, R * 4);
       return kOk;
     }
@@ -318,8 +331,8 @@ int bwtgpu_occ_host(const bwtgpu_index *ix, const uint8_t *h_c, const uint32_t *
       memcpy(io, h_idx, R * 4);
       memcpy(cs, h_c, R);
       BWT_TRY(bwtgpu_occ_batch(ix, box.on_device<uint8_t>(cs), box.on_device<uint32_t>(io), R, skip_dollar_row,
-                               box.on_device<uint32_t>(io + kBoxReads), nullptr));
-      BWT_HIP(hipStreamSynchronize(nullptr));
+                               box.on_device<uint32_t>(io + kBoxReads), box.stream));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       memcpy(h_out, io + kBoxReads, R * 4);
       return kOk;
     }
@@ -346,8 +359,8 @@ int bwtgpu_lf_host(const bwtgpu_index *ix, const uint32_t *h_rows, uint64_t R, u
     if (R <= kBoxReads && box.open(ix->device)) {
       uint32_t *io = reinterpret_cast<uint32_t *>(box.host);
       memcpy(io, h_rows, R * 4);
-      BWT_TRY(bwtgpu_lf_batch(ix, box.on_device<uint32_t>(io), R, box.on_device<uint32_t>(io + kBoxReads), nullptr));
-      BWT_HIP(hipStreamSynchronize(nullptr));
+      BWT_TRY(bwtgpu_lf_batch(ix, box.on_device<uint32_t>(io), R, box.on_device<uint32_t>(io + kBoxReads), box.stream));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       memcpy(h_out, io + kBoxReads, R * 4);
       return kOk;
     }

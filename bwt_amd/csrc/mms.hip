@@ -204,8 +204,8 @@ int bwtgpu_mms_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, u
       uint32_t *res = reinterpret_cast<uint32_t *>(box.host + 32 * 1024 + 256);
       uint32_t *d_res = box.on_device<uint32_t>(res);
       BWT_TRY(bwtgpu_mms(ix, box.dev, m, stride, R, reinterpret_cast<int32_t *>(d_res), d_res + 256, d_res + 512,
-                         nullptr));
-      BWT_HIP(hipStreamSynchronize(nullptr));
+                         box.stream));
+      BWT_HIP(hipStreamSynchronize(box.stream));
       memcpy(h_matched, res, R * 4);
       memcpy(h_sp, res + 256, R * 4);
       memcpy(h_ep, res + 512, R * 4);

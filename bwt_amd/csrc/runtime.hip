@@ -149,6 +149,13 @@ bool Mailbox::open(int device_ordinal) {
     if (h) (void)hipHostFree(h);
     return false;
   }
+  if (stream) (void)hipStreamDestroy(stream);
+  stream = nullptr;
+  if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostFree(h);
+    return false;
+  }
   host = static_cast<uint8_t *>(h);
   dev = static_cast<uint8_t *>(d);
   device = device_ordinal;
