@@ -297,8 +297,12 @@ def main():
             ixs.close()
             tt = torch.tensor([ts], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return {"how": how, "wall_ms": float(tt.item()) * 1e3, "value": n / float(tt.item()) / 1e6,
+            t_max = float(tt.item())
+            return {"how": how, "wall_ms": t_max * 1e3, "value": n / t_max / 1e6,
                     "unit": "Mbp/s", "same_as_whole_build": bool(same),
+                    "roofline": {"bound": "hbm", "bytes_per_bp": 5.625, "achieved": 5.625 * n / t_max / 1e9,
+                                 "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                                 "frac": 5.625 * n / t_max / 1e9 / (HBM_PEAK_GBS * world)},
                     "what": "text replicated, one bucket range of the SA sorted per rank, shards all-gathered "
                             "over RCCL, every rank finishes its own index"}
         except Exception as e:  # noqa: BLE001 - the search figures do not depend on this
