@@ -13,6 +13,8 @@
 
 namespace bwtgpu {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a 16-byte load the non-temporal builtin accepts
+
 constexpr int kPackThreads = 256;
 constexpr uint32_t kPackLdsBytes = 48 * 1024;
 
@@ -113,7 +115,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     const uint8_t *asrc = src - mis;  // see k_pack_reads
     const uint32_t total = mis + span, vecs = total / 16;
     for (uint32_t i = t; i < vecs; i += nt)
-      reinterpret_cast<uint4 *>(bytes)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
+      reinterpret_cast<u32x4 *>(bytes)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(asrc) + i);
     for (uint32_t i = vecs * 16 + t; i < total; i += nt) bytes[i] = asrc[i];
     __syncthreads();
     if (r < R) {
@@ -245,9 +247,10 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
       early = jbad > 0;  // a further base remained, so loc_search sees the empty interval and stops
     }
   }
-  d_sp[r] = sp;
-  d_ep[r] = ep;
-  if (d_locrow) d_locrow[r] = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
+  // results are written once and read by nobody here: streamed past the caches
+  __builtin_nontemporal_store(sp, d_sp + r);
+  __builtin_nontemporal_store(ep, d_ep + r);
+  if (d_locrow) __builtin_nontemporal_store(early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp), d_locrow + r);
   }
   if (COUNT) {
     if (r >= R) n_pat = 0;
