@@ -203,6 +203,10 @@ constexpr int kWave = 64;
 inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
+// search.hip: resolves, once per device and with that device current, the
+// address of the static scratch array bwtgpu_search_static uses.
+int static_scratch_setup(int device, void **out = nullptr);
+
 // index.hip
 int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known

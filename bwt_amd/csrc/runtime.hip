@@ -214,7 +214,8 @@ int bwtgpu_init(int device) {
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(kErrDevice, "device %d is %s; this library is built for gfx950 only",
                      device, prop.gcnArchName);
-  return kOk;
+  // the one thing bwtgpu_search_static would otherwise set up on its first call
+  return static_scratch_setup(device);
 }
 
 int bwtgpu_timing_enable(int on) {

@@ -8,6 +8,8 @@
 // inverse and the text finishes from the text once a single row is left and
 // locates with one lookup.  Every form is bound by the rate of random cache-line
 // fetches, so what these shortcuts buy is fewer lines per read, not fewer bytes.
+#include <mutex>
+
 #include "common.hpp"
 #include "fm_device.hpp"
 
@@ -396,6 +398,37 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
   }
 }
 
+// Scratch of bwtgpu_search_static: the packed reads of a batch whose reads are
+// too long to be packed inside k_search.  One copy per GPU, held by the code
+// object until the process ends.  The name below is only the host's handle on
+// the symbol: the address kernels get is the one hipGetSymbolAddress returns
+// for the current device (static_scratch_setup), kept in g_scratch_ptr.
+constexpr size_t kStaticScratchBytes = 16u << 20;
+static __device__ __align__(256) uint8_t scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+int static_scratch_setup(int device, void **out) {
+  if (device < 0 || device >= kMaxDevices) return set_error(kErrArg, "device %d out of range", device);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[device]) {
+    if (out) *out = g_scratch_ptr[device];
+    return kOk;
+  }
+  int cur = -1;
+  BWT_HIP(hipGetDevice(&cur));
+  if (cur != device) return set_error(kErrArg, "device %d is not the current device (%d)", device, cur);
+  void *p = nullptr;
+  const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !p)
+    return set_error(kErrHip, "address of the static search scratch on device %d: %s", device,
+                     hipGetErrorString(e));
+  g_scratch_ptr[device] = p;
+  if (out) *out = p;
+  return kOk;
+}
+
 }  // namespace bwtgpu
 
 using namespace bwtgpu;
@@ -408,6 +441,21 @@ size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m) {
 
 constexpr uint32_t kFusedLdsBytes = 40 * 1024;
 
+// Reads per workgroup (256, 128 or 64) with which the bytes and packed words of
+// a workgroup's reads fit kFusedLdsBytes, so that k_search packs them itself and
+// the packed-read workspace is never touched; 0 when even 64 reads do not fit.
+static uint32_t fused_group_reads(uint32_t m, uint64_t stride, uint64_t R, uint64_t *lds_bytes) {
+  for (uint32_t nt = 256; nt >= 64; nt /= 2) {
+    const uint64_t bytes = align_up((uint64_t)(nt - 1) * stride + m + 16, 16);
+    const uint64_t fused_lds = bytes + (uint64_t)((m + 15) / 16) * nt * 4;
+    if (fused_lds > kFusedLdsBytes) continue;
+    if (div_up(R, nt) > 0x7FFFFFFFull) return 0;
+    *lds_bytes = fused_lds;
+    return nt;
+  }
+  return 0;
+}
+
 static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                        uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                        size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
@@ -415,7 +463,9 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
   if (R == 0) return kOk;
   if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
-  if (ws_bytes < bwtgpu_search_workspace_bytes(R, m))
+  uint64_t fused_lds = 0;
+  const uint32_t fused_nt = d_counters ? 0u : fused_group_reads(m, stride, R, &fused_lds);
+  if (!fused_nt && ws_bytes < bwtgpu_search_workspace_bytes(R, m))
     return set_error(kErrWorkspace, "search workspace %zu < %zu bytes", ws_bytes,
                      bwtgpu_search_workspace_bytes(R, m));
   if ((uintptr_t)d_ws & 255u) return set_error(kErrArg, "workspace must be 256-byte aligned");
@@ -429,23 +479,16 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   const IndexView v = view_of(ix);
   // bytes and packed words of a workgroup's reads in LDS: pack inside the search kernel.
   // Long reads get smaller workgroups so that they still fit.
-  if (!d_counters) {
-    for (uint32_t nt = 256; nt >= 64; nt /= 2) {
-      const uint64_t bytes = align_up((uint64_t)(nt - 1) * stride + m + 16, 16);
-      const uint64_t fused_lds = bytes + (uint64_t)((m + 15) / 16) * nt * 4;
-      if (fused_lds > kFusedLdsBytes) continue;
-      const uint64_t wgs = div_up(R, nt);
-      if (wgs > 0x7FFFFFFFull) break;
-      const dim3 fgrid((unsigned)wgs), fblock(nt);
-      if (ix->d_sa)
-        BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                   d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
-      else
-        BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                   d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
-      BWT_CHECK_LAUNCH();
-      return kOk;
-    }
+  if (fused_nt) {
+    const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
+    if (ix->d_sa)
+      BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+    else
+      BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+    BWT_CHECK_LAUNCH();
+    return kOk;
   }
   const int use_lds = span <= kPackLdsBytes;
   BWT_LAUNCH("pack_reads", k_pack_reads, dim3((unsigned)groups), dim3(kPackThreads),
@@ -473,6 +516,29 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
                   uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                   size_t ws_bytes, void *stream) {
   return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_ws, ws_bytes, nullptr,
+                     (hipStream_t)stream);
+}
+
+int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+                         uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *stream) {
+  if (!ix) return set_error(kErrArg, "null argument");
+  int dev = -1;
+  BWT_HIP(hipGetDevice(&dev));
+  if (dev != ix->device)
+    return set_error(kErrArg, "the index lives on device %d, the current device is %d", ix->device, dev);
+  // already resolved when bwtgpu_init ran on this device; the first call on a device does it otherwise
+  void *d_scratch = nullptr;
+  BWT_TRY(static_scratch_setup(dev, &d_scratch));
+  // reads short enough to be packed inside the kernel use no scratch at all;
+  // longer ones must fit their packed words into the static array
+  uint64_t lds = 0;
+  if (m && m <= 65535 && R && R <= (1ull << 40) && !fused_group_reads(m, stride, R, &lds) &&
+      bwtgpu_search_workspace_bytes(R, m) > kStaticScratchBytes)
+    return set_error(kErrArg,
+                     "%llu reads of %u bases need %zu bytes of scratch, bwtgpu_search_static has %zu: "
+                     "split the batch or use bwtgpu_search with a workspace",
+                     (unsigned long long)R, m, bwtgpu_search_workspace_bytes(R, m), kStaticScratchBytes);
+  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_scratch, kStaticScratchBytes, nullptr,
                      (hipStream_t)stream);
 }
 

@@ -132,6 +132,17 @@ class GpuIndex:
                                 _ptr(ws), ws.numel(), _stream()))
         return (sp, ep, lr) if want_locrow else (sp, ep)
 
+    def search_static(self, d_pats, m, R, stride=None, want_locrow=False):
+        """bwtgpu_search_static: the same search with the library's own static
+        scratch in place of a workspace argument."""
+        stride = m if stride is None else stride
+        sp = torch.empty(R, dtype=torch.int32, device="cuda")
+        ep = torch.empty(R, dtype=torch.int32, device="cuda")
+        lr = torch.empty(R, dtype=torch.int32, device="cuda") if want_locrow else None
+        check(_lib.load().bwtgpu_search_static(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(lr),
+                                               _stream()))
+        return (sp, ep, lr) if want_locrow else (sp, ep)
+
     def search_loads(self, d_pats, m, R, stride=None):
         """Loads one search of the batch makes: dict of counts (see
         bwtgpu_search_profile) and the bytes they add up to."""

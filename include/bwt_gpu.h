@@ -151,11 +151,33 @@ int bwtgpu_index_compact(bwtgpu_index *ix);
  * the last step), or 0xFFFFFFFE where sp = n+1 (the reference reads out of
  * bounds there); bwtgpu_locate_rows maps both to "no position".
  * Only the low two bits of a pattern byte are used.
+ * The kernels read the reads in aligned 16-byte pieces, so up to 15 bytes in
+ * front of d_pats (back to the previous 16-byte boundary) and up to 16 bytes
+ * past the last read are loaded and ignored: both must be readable, which they
+ * are when d_pats lies inside a device allocation whose base is 16-byte aligned
+ * (hipMalloc and torch give 256) and that extends 16 bytes past the last read.
  * Workspace: bwtgpu_search_workspace_bytes(R, m) bytes, 256-byte aligned. */
 size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m);
 int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                   uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
                   uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
+/* bwtgpu_search for callers that cannot allocate or hold a workspace (code
+ * under HIP graph capture, tight serving loops): no counterpart in the
+ * reference.  Same inputs, outputs and results as bwtgpu_search; the packed-read
+ * workspace is a 16 MiB array that lives in the library's code object on every
+ * GPU the library runs on (its address on a device is resolved by bwtgpu_init,
+ * or by the first call on that device).  The call itself allocates nothing.
+ * Reads short enough to be packed inside the search kernel (up to about 500
+ * bases at stride = m) use no scratch and any R is accepted; for longer reads
+ * ((m+15)/16) * 4 * R + 512 bytes must fit the 16 MiB, else the call fails with
+ * -2 and a message that says so.  All calls on one GPU share that GPU's array:
+ * two calls with long reads that overlap in time on one GPU race, so keep them
+ * on one stream or order them yourself.  The index must live on the current
+ * device.  (With launch timing enabled, bwtgpu_timing_enable, the HIP events
+ * it records are created per launch.) */
+int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
+                         uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
+                         uint32_t *d_locrow, void *stream);
 /* bwtgpu_search, and the number of loads the batch made: loads[0] 16-byte rank
  * blocks, loads[1] 16-byte text windows, loads[2] 4-byte SA/ISA entries,
  * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table lookups.
