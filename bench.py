@@ -191,9 +191,12 @@ def main():
     # ---- HP1: FM-index build from the HBM-resident text ----
     # wall time over build_reps builds with launch timing off (two HIP events per
     # launch are not free), then one more build with it on for the per-kernel split
+    # The build proper ends when what make_fmi produces is in HBM; the arrays that only
+    # speed searches up (position records, k-mer table) are made on first search and are
+    # timed here as their own item.
     G.timing_enable(False)
     ix = None
-    build_ms = []
+    build_ms, prep_ms = [], []
     for rep in range(args.build_reps + 1):
         if ix is not None:
             ix.close()
@@ -201,16 +204,26 @@ def main():
         t0 = time.perf_counter()
         ix = G.build_index_dev(d_text, n)
         torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ix.prepare_search()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
         if rep >= 1 or args.build_reps == 0:
-            build_ms.append((time.perf_counter() - t0) * 1e3)
+            build_ms.append((t1 - t0) * 1e3)
+            prep_ms.append((t2 - t1) * 1e3)
     ix.close()
     G.timing_enable(True)
     G.timing_reset()
     ix = G.build_index_dev(d_text, n)
     torch.cuda.synchronize()
     build_kernels = G.timing_report()
+    G.timing_reset()
+    ix.prepare_search()
+    torch.cuda.synchronize()
+    prep_kernels = G.timing_report()
     sa_stats = G.sa_last_stats()
     build_s = float(np.median(build_ms)) / 1e3
+    prep_s = float(np.median(prep_ms)) / 1e3
 
     sharded = None
     if dist is None:
@@ -422,9 +435,16 @@ def main():
             "value": n / build_s / 1e6,
             "unit": "Mbp/s",
             "wall_ms": build_s * 1e3,
-            "what": "make_fmi on device: text in HBM -> SA, BWT, sampled SA, rank blocks, C[], "
-                    "plus inverse SA and word-packed text kept for search",
+            "what": "make_fmi on device: text in HBM -> SA, BWT, sampled SA, rank blocks, C[] "
+                    "(whole SA and word-packed text kept in HBM)",
             "sa_kernels_ms": sa_ms,
+            "search_arrays": {
+                "what": "position records (inverse SA + text) and k-mer table, made once on first search",
+                "wall_ms": prep_s * 1e3,
+                "kernels_ms": {k: round(v[1], 4) for k, v in sorted(prep_kernels.items())},
+            },
+            "with_search_arrays": {"wall_ms": (build_s + prep_s) * 1e3,
+                                   "value": n / (build_s + prep_s) / 1e6, "unit": "Mbp/s"},
             "roofline": {
                 "bound": "hbm", "bytes_per_bp": 5.625,
                 "achieved": 5.625 * n / build_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

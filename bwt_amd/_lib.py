@@ -66,6 +66,10 @@ SIGNATURES = {
     "bwtgpu_index_build_from_sa": (vp, [vp, u32, vp, vp, u32, vp]),
     "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
     "bwtgpu_index_compact": (C.c_int, [vp]),
+    "bwtgpu_sa_certify_workspace_bytes": (sz, [u32]),
+    "bwtgpu_sa_certify": (C.c_int, [vp, u32, vp, vp, sz, C.POINTER(u64), vp]),
+    "bwtgpu_index_certify": (C.c_int, [vp, vp, vp, sz, C.POINTER(u64), vp]),
+    "bwtgpu_index_prepare_search": (C.c_int, [vp, vp]),
     "bwtgpu_index_attach_text": (C.c_int, [vp, vp, vp]),
     "bwtgpu_index_attach_text_dev": (C.c_int, [vp, vp, vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),

@@ -188,6 +188,7 @@ extern "C" int bwtgpu_align_reads(const bwtgpu_index *ix, const uint8_t *d_text,
   const uint32_t lds_bytes = L.total + (uint32_t)align_up(max_len + 1, 4);
   if (lds_bytes > 64u * 1024u)
     return set_error(kErrArg, "reads of %u bases need %u bytes of LDS (64 KiB at most)", max_len, lds_bytes);
+  BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   BWT_LAUNCH("align_reads", k_align_reads, dim3((unsigned)R), dim3(64), lds_bytes, (hipStream_t)stream,

@@ -7,7 +7,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -194,6 +196,15 @@ struct bwtgpu_index {
   uint32_t *d_kmer = nullptr;
   uint32_t kmer_k = 0;
   int device = 0;
+  // What make_fmi (seqindex.c:161-189) produces is complete when a build or a
+  // load returns.  The arrays that only speed searches up (position records,
+  // k-mer table) are made by index_prepare_search, which the search entry
+  // points call on first use: a caller that builds an index to write it to a
+  // file never pays for them.  want_*: the array can be and is to be made.
+  bool want_records = false;  // d_sa and d_text2 are in place
+  bool want_kmer = false;
+  mutable std::atomic<bool> search_ready{true};  // nothing left for index_prepare_search to do
+  mutable std::mutex prepare_mu;
 };
 
 namespace bwtgpu {
@@ -210,6 +221,16 @@ int static_scratch_setup(int device, void **out = nullptr);
 // index.hip
 int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known
+// Makes the search-only arrays an index still lacks (see bwtgpu_index); safe to
+// call from several threads, returns at once when there is nothing to do, and
+// waits for `s` when it did something, so that any stream may search afterwards.
+int index_prepare_search(const bwtgpu_index *ix, hipStream_t s);
+inline int index_ready_for_search(const bwtgpu_index *ix, hipStream_t s) {
+  return ix->search_ready.load(std::memory_order_acquire) ? 0 : index_prepare_search(ix, s);
+}
+void index_defer_search_arrays(bwtgpu_index *ix);
+// fm_build.hip: the position records of an index that holds d_sa and d_text2
+int index_build_records(bwtgpu_index *ix, hipStream_t s);
 int index_alloc(bwtgpu_index **out, uint32_t n);
 
 // sa_build.hip

@@ -378,30 +378,29 @@ static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
   return kOk;
 }
 
-// Allocates the arrays an index keeps beside what make_fmi produces, unless
-// asked not to or HBM is short.
+// Allocates what an index keeps beside what make_fmi produces, unless asked not
+// to or HBM is short: room for the whole suffix array (the sort then writes its
+// rows there) and for the text in words.  The position records are made from
+// the two when a search first needs them (index_build_records).
 static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
   if (getenv("BWT_MI355X_COMPACT") || n > kPosRecordMaxN) return;
   const uint64_t rows_all = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   hipError_t ea = pool_alloc(&ix->d_sa, rows_all * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord));
   if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
   if (ea != hipSuccess) {
     (void)hipGetLastError();
     pool_free(ix->d_sa);
-    pool_free(ix->d_isa);
     pool_free(ix->d_text2);
-    ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+    ix->d_sa = ix->d_text2 = nullptr;
   }
 }
 
-// Everything after the suffix array: BWT bit-planes, sampled rows, the kept
-// arrays, rank blocks, C[], the k-mer table.  d_sa holds the n+1 rows (it is
+// Everything after the suffix array: BWT bit-planes, sampled rows, the text in
+// words, rank blocks, C[].  d_sa holds the n+1 rows (it is
 // ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
 // rows 1..n and *d_endloc then already holds the $ row.
 static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
-                      const uint8_t *bw, uint32_t *d_endloc, void *isa_scratch, bool have_samples,
-                      hipStream_t s) {
+                      const uint8_t *bw, uint32_t *d_endloc, bool have_samples, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
     BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows,
@@ -417,17 +416,51 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
   const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
   if (!have_samples)  // else the leaf sort dropped them as it wrote the rows
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
-  if (ix->d_sa) {
+  if (ix->d_sa)  // the caller's text may be gone by the time a search wants the records
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
-    BWT_TRY(inverse_suffix_array(d_sa, n, ix->d_text2, ix->d_isa, isa_scratch, s));
-  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
   BWT_TRY(index_finish_from_planes(ix, s));  // synchronises the stream
   if (ix->endloc > n) return set_error(kErrInternal, "no suffix-array row holds suffix 0");
-  return index_build_kmer_table(ix, s);
+  // what make_fmi produces is complete; the search-only arrays wait for the first search
+  index_defer_search_arrays(ix);
+  return kOk;
+}
+
+// The position records (see PosRecord) of an index that holds its suffix array
+// and the text in words.  Not an error when HBM is short: the index then
+// searches on its rank blocks alone.
+int index_build_records(bwtgpu_index *ix, hipStream_t s) {
+  if (!ix->d_sa || !ix->d_text2 || ix->d_isa) return kOk;
+  const uint32_t n = ix->n;
+  if (pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord)) != hipSuccess) {
+    (void)hipGetLastError();
+    ix->d_isa = nullptr;
+    return kOk;
+  }
+  // scratch for the two-step scatter: the calling thread's idle build workspace
+  // when it is large enough (the build that has just returned left it), else a
+  // buffer of its own
+  void *scratch = nullptr, *own = nullptr;
+  int dev = -1;
+  (void)hipGetDevice(&dev);
+  if (g_cache.device == dev && g_cache.ws && g_cache.ws_bytes >= bwtgpu_sa_workspace_bytes(n))
+    scratch = sa_workspace_free_region(n, g_cache.ws);
+  if (!scratch && (uint64_t)n + 1 > (1ull << 22)) {
+    if (pool_alloc(&own, ((size_t)n + 1) * 8 + 2048) == hipSuccess) scratch = own;
+    else (void)hipGetLastError();  // the one-step scatter needs none
+  }
+  int rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, ix->d_isa, scratch, s);
+  if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "position records failed");
+  if (rc != kOk) (void)hipDeviceSynchronize();
+  pool_free(own);
+  if (rc != kOk) {
+    pool_free(ix->d_isa);
+    ix->d_isa = nullptr;
+  }
+  return rc;
 }
 
 static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t s,
@@ -448,9 +481,7 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
     if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
-    // the sort's id and key buffers (12 bytes per row, contiguous) are free again
-    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, sa_workspace_free_region(n, g_cache.ws),
-                    extras.samples_done, s);
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, extras.samples_done, s);
   }
   if (rc != kOk) {
     bwtgpu_index_free(ix);
@@ -568,14 +599,7 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     rc = set_error(kErrHip, "suffix array copy failed");
   if (rc == kOk && d_bw && hipMemcpyAsync(d_endloc, &endloc, 4, hipMemcpyHostToDevice, s) != hipSuccess)
     rc = set_error(kErrHip, "endloc upload failed");
-  void *scratch = nullptr;
-  if (rc == kOk && ix->d_sa && (uint64_t)n + 1 > (1ull << 22) &&
-      hipMalloc(&scratch, ((size_t)n + 1) * 8 + 2048) != hipSuccess) {
-    (void)hipGetLastError();
-    scratch = nullptr;  // the one-step scatter needs none
-  }
-  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, scratch, false, s);
-  if (scratch) (void)hipFree(scratch);  // emit_index has synchronised the stream
+  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, false, s);
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return nullptr;
@@ -591,15 +615,14 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   const uint32_t n = ix->n;
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (n > kPosRecordMaxN) return set_error(kErrArg, "text of %u bases is too long to keep beside its index", n);
+  std::lock_guard<std::mutex> lock(ix->prepare_mu);
   hipError_t ea = pool_alloc(&ix->d_sa, rows * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord));
   if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
   auto drop = [&]() {
     (void)hipDeviceSynchronize();
     pool_free(ix->d_sa);
-    pool_free(ix->d_isa);
     pool_free(ix->d_text2);
-    ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
+    ix->d_sa = ix->d_text2 = nullptr;
   };
   if (ea != hipSuccess) {
     (void)hipGetLastError();
@@ -632,14 +655,17 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   if (rc == kOk) {
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
-    rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, ix->d_isa, sa_workspace_free_region(n, g_cache.ws), s);
-    if (rc == kOk) {
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-        rc = set_error(kErrHip, "attaching the text failed");
-    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      rc = set_error(kErrHip, "attaching the text failed");
   }
-  if (rc != kOk) drop();
-  return rc;
+  if (rc != kOk) {
+    drop();
+    return rc;
+  }
+  // the position records follow when a search first wants them
+  ix->want_records = true;
+  ix->search_ready.store(false, std::memory_order_release);
+  return kOk;
 }
 
 int bwtgpu_index_attach_text(bwtgpu_index *ix, const uint8_t *h_text, void *stream) {

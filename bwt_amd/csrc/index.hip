@@ -488,6 +488,31 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   return kOk;
 }
 
+// Called when what make_fmi produces is in place: notes which search-only
+// arrays this index can still get.
+void index_defer_search_arrays(bwtgpu_index *ix) {
+  ix->want_records = ix->d_sa && ix->d_text2 && !ix->d_isa;
+  ix->want_kmer = !ix->d_kmer && kmer_table_k(ix->n) != 0;
+  ix->search_ready.store(!(ix->want_records || ix->want_kmer), std::memory_order_release);
+}
+
+int index_prepare_search(const bwtgpu_index *cix, hipStream_t s) {
+  bwtgpu_index *ix = const_cast<bwtgpu_index *>(cix);
+  std::lock_guard<std::mutex> lock(ix->prepare_mu);
+  if (ix->search_ready.load(std::memory_order_acquire)) return kOk;
+  int cur = -1;
+  BWT_HIP(hipGetDevice(&cur));
+  if (cur != ix->device) BWT_HIP(hipSetDevice(ix->device));
+  int rc = kOk;
+  if (ix->want_records) rc = index_build_records(ix, s);
+  if (rc == kOk && ix->want_kmer) rc = index_build_kmer_table(ix, s);  // synchronises the stream
+  if (cur != ix->device) (void)hipSetDevice(cur);
+  if (rc != kOk) return rc;
+  ix->want_records = ix->want_kmer = false;
+  ix->search_ready.store(true, std::memory_order_release);
+  return kOk;
+}
+
 int index_alloc(bwtgpu_index **out, uint32_t n) {
   if (n == 0 || n > 0xFFFFFFF0u)
     return set_error(kErrArg, "text length %u out of range", n);
@@ -599,7 +624,7 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
                        reinterpret_cast<const uint4 *>(d_bwt), ix->d_blocks, nb, n);
   }
   int rc = index_finish_from_planes(ix, s);
-  if (rc == kOk) rc = index_build_kmer_table(ix, s);
+  if (rc == kOk) index_defer_search_arrays(ix);  // the k-mer table waits for the first search
   if (rc == kOk && h_idxs) {
     ScopedKernelTimer t("densify_samples", s);
     hipLaunchKernelGGL(k_densify_samples, dim3((unsigned)div_up(ndense, 256)), dim3(256), 0, s,
@@ -628,7 +653,8 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
-         (ix->d_sa ? ((size_t)ix->n + 1) * 4 + pos_record_count(ix->n) * sizeof(PosRecord) + ((size_t)ix->n / 16 + 4) * 4 : 0) +
+         (ix->d_sa ? ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
+         (ix->d_isa ? pos_record_count(ix->n) * sizeof(PosRecord) : 0) +
          (ix->d_kmer ? ((1ull << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2) : 0);
 }
 
@@ -636,6 +662,7 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   if (!ix) return set_error(kErrArg, "null index");
   BWT_HIP(hipSetDevice(ix->device));
   BWT_HIP(hipDeviceSynchronize());  // searches in flight may still read the arrays
+  std::lock_guard<std::mutex> lock(ix->prepare_mu);
   // compacting is for saving memory: these go back to the driver, not to the pool
   pool_free(ix->d_sa);
   pool_free(ix->d_isa);
@@ -645,7 +672,14 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
   ix->kmer_k = 0;
+  ix->want_records = ix->want_kmer = false;
+  ix->search_ready.store(true, std::memory_order_release);
   return kOk;
+}
+
+int bwtgpu_index_prepare_search(bwtgpu_index *ix, void *stream) {
+  if (!ix) return set_error(kErrArg, "null index");
+  return index_ready_for_search(ix, (hipStream_t)stream);
 }
 
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {

@@ -142,6 +142,7 @@ int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64
   if (!ix || !d_pats || !d_matched || !d_sp || !d_ep) return set_error(kErrArg, "null argument");
   if (m == 0 || m > 0x7FFFFFFFu) return set_error(kErrArg, "pattern length out of range");
   if (R == 0) return kOk;
+  BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   // patterns of a workgroup through LDS when they fit (smaller workgroups for long patterns)
@@ -166,6 +167,7 @@ int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads, const ui
   if (!ix || !d_reads || !d_reversed || !d_offsets || !d_out) return set_error(kErrArg, "null argument");
   if (anchor < 1) return set_error(kErrArg, "anchor length must be positive");
   if (R == 0) return kOk;
+  BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   hipStream_t s = (hipStream_t)stream;

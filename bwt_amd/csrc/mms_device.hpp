@@ -120,7 +120,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     if (end <= start) break;
     sp = start;
     ep = end;
-    if (v.sa && end - start == 1) {
+    if (v.isa && end - start == 1) {
       const uint32_t pos = v.sa[start];
       uint32_t k = 0;  // bases that agree with the text in front of pos
       if (WAVE) {

@@ -481,7 +481,7 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   // Long reads get smaller workgroups so that they still fit.
   if (fused_nt) {
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
-    if (ix->d_sa)
+    if (ix->d_isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
                  d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
     else
@@ -495,13 +495,13 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
              use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
   BWT_CHECK_LAUNCH();
   if (d_counters) {
-    if (ix->d_sa)
+    if (ix->d_isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_counters);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_counters);
-  } else if (ix->d_sa) {
+  } else if (ix->d_isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
                d_sp, d_ep, d_locrow, d_counters);
   } else {
@@ -515,6 +515,7 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
 int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                   uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                   size_t ws_bytes, void *stream) {
+  if (ix) BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_ws, ws_bytes, nullptr,
                      (hipStream_t)stream);
 }
@@ -553,6 +554,7 @@ int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_
                      bwtgpu_search_workspace_bytes(R, m) + 256);
   if (!d_ws || ((uintptr_t)d_ws & 255u)) return set_error(kErrArg, "workspace must be 256-byte aligned");
   unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_ws);
+  if (ix) BWT_TRY(index_ready_for_search(ix, s));
   BWT_HIP(hipMemsetAsync(ctr, 0, 256, s));
   BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
                       s));

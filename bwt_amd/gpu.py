@@ -174,6 +174,19 @@ class GpuIndex:
         """Drop the kept suffix array, its inverse and the text (see bwtgpu_index_compact)."""
         check(_lib.load().bwtgpu_index_compact(self.h))
 
+    def certify(self, d_text):
+        """bwtgpu_index_certify: dict of violation counts, all zero for a correct index."""
+        lib = _lib.load()
+        ws = torch.empty(int(lib.bwtgpu_sa_certify_workspace_bytes(self.n)), dtype=torch.uint8, device="cuda")
+        rep = (C.c_uint64 * 8)()
+        check(lib.bwtgpu_index_certify(self.h, _ptr(d_text), _ptr(ws), ws.numel(), rep, _stream()))
+        return dict(zip(("out_of_range", "not_a_permutation", "order", "bwt_blocks", "samples", "endloc"),
+                        (int(x) for x in rep)))
+
+    def prepare_search(self):
+        """Make the search-only arrays now (see bwtgpu_index_prepare_search)."""
+        check(_lib.load().bwtgpu_index_prepare_search(self.h, _stream()))
+
     def locate_rows(self, d_rows, count_steps=False, out=None):
         lib = _lib.load()
         R = d_rows.numel()
@@ -221,6 +234,15 @@ def sa_build(d_text, n, ws=None):
         ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
     check(lib.bwtgpu_sa_build(_ptr(d_text), n, _ptr(sa), _ptr(ws), ws.numel(), _stream()))
     return sa
+
+
+def sa_certify(d_text, n, d_sa):
+    """bwtgpu_sa_certify: (out_of_range, not_a_permutation, order) violation counts."""
+    lib = _lib.load()
+    ws = torch.empty(int(lib.bwtgpu_sa_certify_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
+    rep = (C.c_uint64 * 8)()
+    check(lib.bwtgpu_sa_certify(_ptr(d_text), n, _ptr(d_sa), _ptr(ws), ws.numel(), rep, _stream()))
+    return int(rep[0]), int(rep[1]), int(rep[2])
 
 
 def sa_bucket_counts(d_text, n):

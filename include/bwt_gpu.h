@@ -139,6 +139,37 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
  * array.  Setting BWT_MI355X_COMPACT in the environment makes every build and
  * load do so.  No counterpart in the reference. */
 int bwtgpu_index_compact(bwtgpu_index *ix);
+/* A build or load returns as soon as what make_fmi produces (seqindex.c:161-189:
+ * BWT, sampled rows, rank blocks, C[], the $ row) is in place; the arrays that
+ * only speed searches up -- position records, k-mer table, 5.3 + about 4 bytes
+ * per base -- are made by the first bwtgpu_search / _mms / _search_reads /
+ * _align_reads call on the index (once; concurrent first calls wait for each
+ * other), so an index that is built only to be written to a file never pays
+ * for them.  This call makes them now, on `stream`, and waits for it.  When HBM
+ * is short they are left out, which is not an error.  No counterpart in the
+ * reference. */
+int bwtgpu_index_prepare_search(bwtgpu_index *ix, void *stream);
+
+/* ---- certificates (no counterpart in the reference: its lengths are int, so
+ * beyond 2^31 - 1 bases there is no reference output to compare with) ---- */
+/* Is d_sa[0..n] the suffix array of the packed text (row 0 = n, then all
+ * suffixes in order, the end of the text smallest: histsortcomp.c:161-180)?
+ * Checked on the device in O(n) with an inverse built in the workspace
+ * (bwtgpu_sa_certify_workspace_bytes(n) = 4(n+1) + 256 bytes, 256-byte
+ * aligned): report[0] = values out of range or row 0 != n, report[1] =
+ * positions that no row, or more than one, holds, report[2] = neighbouring
+ * rows in the wrong order.  All zero <=> the array is correct. */
+size_t bwtgpu_sa_certify_workspace_bytes(uint32_t n);
+int bwtgpu_sa_certify(const uint8_t *d_text, uint32_t n, const uint32_t *d_sa, void *d_ws,
+                      size_t ws_bytes, uint64_t report[8], void *stream);
+/* The same for the suffix array an index built from the text keeps, and then
+ * the rest of what make_fmi (seqindex.c:161-189) derives from it: report[3] =
+ * 64-base blocks whose BWT differs from text[SA[row] - 1] (sprintcbwt,
+ * histsortcomp.c:220-250), report[4] = sampled rows that differ from SA
+ * (seqindex.c:173-176), report[5] = 1 if the $ row does not hold suffix 0.
+ * Fails with -2 on an index that keeps no suffix array.  Same workspace. */
+int bwtgpu_index_certify(const bwtgpu_index *ix, const uint8_t *d_text, void *d_ws,
+                         size_t ws_bytes, uint64_t report[8], void *stream);
 
 /* ---- backward search (HP2) ---- */
 /* Replaces the host loop over loc_search (seqindex.c:280-309; the worker loop
@@ -166,7 +197,9 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
  * reference.  Same inputs, outputs and results as bwtgpu_search; the packed-read
  * workspace is a 16 MiB array that lives in the library's code object on every
  * GPU the library runs on (its address on a device is resolved by bwtgpu_init,
- * or by the first call on that device).  The call itself allocates nothing.
+ * or by the first call on that device).  The call itself allocates nothing,
+ * which includes the search-only arrays of bwtgpu_index_prepare_search: it
+ * uses them when they are there and searches on the rank blocks when not.
  * Reads short enough to be packed inside the search kernel (up to about 500
  * bases at stride = m) use no scratch and any R is accepted; for longer reads
  * ((m+15)/16) * 4 * R + 512 bytes must fit the 16 MiB, else the call fails with

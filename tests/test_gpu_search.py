@@ -195,6 +195,8 @@ def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R
     fo = oracle.make_fmi(text, n, oracle.sa_doubling(text, n) if kind != "random" else None)
     full = gpu.build_index(text, n)
     lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    full.prepare_search()  # the position records and the k-mer table are made on first search otherwise
+    lean.prepare_search()
     assert full.device_bytes > lean.device_bytes + 8 * n
     reads = _mutated_reads(bases, n, R, m, 1234 + n)
     sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
@@ -224,6 +226,7 @@ def test_compact_drops_the_kept_arrays_and_counting_search_agrees(oracle, gpu):
     reads = _mutated_reads(synth.unpack(text, n), n, R, m, 5)
     sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
     d = torch.from_numpy(reads.reshape(-1)).cuda()
+    ix.prepare_search()
     big = ix.device_bytes
     loads_full, sp, ep = ix.search_loads(d, m, R)
     np.testing.assert_array_equal(gpu.to_numpy_u32(sp), sp_o)
@@ -325,12 +328,14 @@ def test_attach_text_to_a_loaded_index(oracle, gpu):
     text = oracle.gen_genome(n, 808)
     fo = oracle.make_fmi(text, n)
     ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix.prepare_search()
     lean_bytes = ix.device_bytes
     other = oracle.gen_genome(n, 809)
     with pytest.raises(gpu.BwtGpuError, match="not the one"):
         ix.attach_text(other)
     assert ix.device_bytes == lean_bytes
     ix.attach_text(text)
+    ix.prepare_search()
     assert ix.device_bytes > lean_bytes + 8 * n
     ix.attach_text(text)  # a second call is a no-op
     reads = _mutated_reads(synth.unpack(text, n), n, R, m, 31)
