@@ -8,6 +8,10 @@ pass over the rank's whole read batch with the reads already in HBM.  At N>1
 the index is replicated per GPU (each rank builds it) and every rank searches
 its own batch of the same size (weak scaling, no data-path collective).
 
+`--config c4` is BASELINE.json configs[3] in the form it names: a 3.1 Gbp genome,
+the index replicated on every GPU, ONE set of 100 M x 100 bp reads partitioned
+over the ranks (strong scaling), locate included in the step.
+
 Prints ONE JSON line on rank 0.  `value` = reads/s over all ranks; the SA/BWT
 build rate, the locate rate, the roofline figures of the dominant kernel and
 the CPU baseline ride in the same line.
@@ -137,14 +141,208 @@ def cpu_baseline(args, d_text, n, d_reads, R, m, gpu_sp, gpu_ep):
     return out
 
 
+def c5_leg(args):
+    """BASELINE.json configs[4]: a 100 Mbp tandem repeat with rare point mutations, the input the
+    reference's histsort cannot sort (README.md:76-77): the prefix-doubling path, certified on
+    the device, next to the reference's csuff_arr (csacak.c:521-528) on one host core."""
+    from oracle import load_oracle, load_reference
+
+    n = 100_000_000
+    orc = load_oracle()
+    text = orc.gen_tandem(n, 1000, 11, 5000, 3)
+    d_text = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
+    G.timing_enable(False)
+    G.sa_build(d_text, n)  # warm-up: workspace
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sa = G.sa_build(d_text, n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = G.sa_last_stats()
+    cert = G.sa_certify(d_text, n, sa)
+    out = {"workload": "100 Mbp tandem repeat, period 1000, a point mutation every 5000 bases on average",
+           "value": n / dt / 1e6, "unit": "Mbp/s", "wall_ms": dt * 1e3,
+           "levels": st[0], "unresolved_rows_after_bucket_sort": st[2], "doubling_rounds": st[3],
+           "certified_on_device": cert == (0, 0, 0),
+           "roofline": {"bound": "hbm", "bytes_per_bp": 4.25, "achieved": 4.25 * n / dt / 1e9, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": 4.25 * n / dt / 1e9 / HBM_PEAK_GBS}}
+    ref = None if (args.no_cpu or args.cpu_port) else load_reference()
+    if ref is not None:
+        t0 = time.perf_counter()
+        sa_ref = ref.csuff_arr(text, n)
+        dc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dc / 1e6, "unit": "Mbp/s", "cores": 1, "kind": "reference",
+                               "sample": "the whole 100 Mbp text through csuff_arr (SACA-K is sequential)",
+                               "seconds": dc,
+                               "gpu_matches_cpu": bool((np.asarray(sa_ref, np.uint32) == G.to_numpy_u32(sa)).all())}
+    del sa, d_text
+    G._lib.load().bwtgpu_release_cache()
+    return out
+
+
+def bench_c4(args, rank, world, dist, barrier, red_dev):
+    """BASELINE.json configs[3]: 3.1 Gbp, index replicated, ONE set of reads partitioned over the
+    ranks (the static split of fmitest.c:67-91), each read searched and located.  Strong scaling:
+    value = reads of the whole set / time of the slowest rank."""
+    from bwt_amd import dist as D
+
+    n, R_all, m = args.genome_bp, args.reads, args.read_len
+    d_text = G.gen_genome(n, synth.GENOME_SEED)
+    torch.cuda.synchronize()
+    G.timing_enable(False)
+    build_ms, prep_ms = [], []
+    ix = None
+    for rep in range(2):  # the second build finds its buffers in the pool
+        if ix is not None:
+            ix.close()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix = G.build_index_dev(d_text, n)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        ix.prepare_search()
+        torch.cuda.synchronize()
+        build_ms.append((t1 - t0) * 1e3)
+        prep_ms.append((time.perf_counter() - t1) * 1e3)
+    sa_stats = G.sa_last_stats()
+    G._lib.load().bwtgpu_release_cache()  # the build workspace (about 17 B/base) goes back before the reads come
+
+    lo, hi = D.slice_bounds(R_all, world, rank)
+    R = hi - lo
+    d_reads, d_offs = G.gen_reads(d_text, n, R, m, synth.READS_SEED, first=lo)
+    sp, ep, lr, pos = (torch.empty(R, dtype=torch.int32, device="cuda") for _ in range(4))
+
+    def step():
+        ix.search(d_reads, m, R, want_locrow=True, out=(sp, ep, lr))
+        ix.locate_rows(lr, out=pos)
+
+    for _ in range(args.warmup):
+        step()
+    G.timing_enable(True)
+    G.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = G.timing_report()
+    G.timing_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # what the text itself says about the answers: every read cut from it is found, every unique one
+    # located where it was cut; and a position-weighted checksum of this slice's three result arrays
+    cut = d_offs != -1
+
+    def u32(x):
+        return x.to(torch.int64) & 0xFFFFFFFF
+
+    found_all = bool((u32(ep[cut]) > u32(sp[cut])).all())
+    uniq = cut & ((ep - sp) == 1)
+    located_ok = bool((pos[uniq] == d_offs[uniq]).all())
+    weight = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device="cuda")
+    sums = torch.stack([(x.to(torch.int64) * weight).sum() for x in (sp, ep, pos)])
+    same_output = None
+    if dist is not None:
+        all_sums = [torch.zeros(3, dtype=torch.int64, device=red_dev) for _ in range(world)]
+        dist.all_gather(all_sums, sums.to(red_dev))
+        flags = torch.tensor([int(found_all), int(located_ok)], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        found_all, located_ok = bool(flags[0]), bool(flags[1])
+        if rank == 0:
+            # the single-rank answers for every other rank's slice, computed here on the same index
+            same_output = True
+            for g in range(1, world):
+                glo, ghi = D.slice_bounds(R_all, world, g)
+                rg, _ = G.gen_reads(d_text, n, ghi - glo, m, synth.READS_SEED, want_offsets=False, first=glo)
+                a, b, c = ix.search(rg, m, ghi - glo, want_locrow=True)
+                p = ix.locate_rows(c)
+                w = torch.arange(glo + 1, ghi + 1, dtype=torch.int64, device="cuda")
+                want = torch.stack([(x.to(torch.int64) * w).sum() for x in (a, b, p)])
+                same_output = same_output and bool(torch.equal(want.cpu(), all_sums[g].cpu()))
+                del rg, a, b, c, p, w
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+
+    ns, ms_s = kernels.get("fm_search", (0, 0.0))
+    nl, ms_l = kernels.get("fm_locate", (0, 0.0))
+    k_ms, l_ms = ms_s / max(ns, 1), ms_l / max(nl, 1)
+    loads, sp_c, ep_c = ix.search_loads(d_reads, m, R)
+    counted_ok = bool(torch.equal(sp_c, sp) and torch.equal(ep_c, ep))
+    bpr = (loads["bytes"] - 4 * loads["pattern_words_4B"]) / R + m + 12.0
+    achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+    traffic = measured_traffic(f"{n}bp_{R_all}x{m}") if world == 1 else None
+    build_s, prep_s = build_ms[-1] / 1e3, prep_ms[-1] / 1e3
+    result = {
+        "metric": "SA build Mbp/s; FM backward-search reads/s (1/2/4/8 GPU); % HBM peak",
+        "value": R_all * args.steps / elapsed,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{n / 1e6:g} Mbp splitmix64 genome, FM-index built on every GPU (replicated), ONE set of "
+                        f"{R_all} x {m} bp reads (1% random) split into contiguous slices over the GPUs, "
+                        f"backward search + locate of every read per step",
+            "genome_bp": n, "reads_total": R_all, "reads_this_rank": R, "read_len": m,
+        },
+        "checks": {"every_cut_read_found": found_all, "unique_reads_located_at_their_offset": located_ok,
+                   "same_output_as_single_rank": same_output},
+        "roofline": {
+            "kernel": "fm_search", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/pmc_fm_search.json (builder's rocprofv3 --pmc passes; looked up)"
+            if traffic is not None else None,
+            "bytes_per_read": bpr, "loads": loads, "counting_pass_matches": counted_ok, "kernel_ms": k_ms,
+            "requested_lines_per_read": (loads["rank_blocks_16B"] + loads["text_windows_16B"]
+                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries_8B"]) / R,
+            "what": "rank 0's slice; bytes counted by the kernel's counting build",
+        },
+        "locate": {"kernel_ms": l_ms, "value": R / (l_ms * 1e-3) if l_ms else None, "unit": "rows/s",
+                   "what": "one SA entry per row"},
+        "sa_build": {
+            "value": n / build_s / 1e6, "unit": "Mbp/s", "wall_ms": build_s * 1e3,
+            "what": "make_fmi on device, whole text on this GPU (every rank builds its replica)",
+            "search_arrays_ms": prep_s * 1e3,
+            "with_search_arrays": {"wall_ms": (build_s + prep_s) * 1e3, "value": n / (build_s + prep_s) / 1e6,
+                                   "unit": "Mbp/s"},
+            "roofline": {"bound": "hbm", "bytes_per_bp": 5.625, "achieved": 5.625 * n / build_s / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 5.625 * n / build_s / 1e9 / HBM_PEAK_GBS},
+            "stats": {"levels": sa_stats[0], "leaves": sa_stats[1], "unresolved_rows": sa_stats[2],
+                      "doubling_rounds": sa_stats[3]},
+        },
+        "cpu_baseline": None,
+        "cpu_baseline_note": "the reference cannot run this configuration: its lengths are int "
+                             "(seqindex.h:14-22, csacak.c:14) and 3.1e9 > 2^31 - 1; see the c2 line for the "
+                             "reference timed on this box",
+        "index_bytes": ix.device_bytes,
+    }
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--genome-bp", type=int, default=46_000_000)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step")
-    ap.add_argument("--read-len", type=int, default=50)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2: 46 Mbp, 10 M x 50 bp per GPU (weak); c4: 3.1 Gbp, 100 M x 100 bp over all GPUs (strong)")
+    ap.add_argument("--genome-bp", type=int, default=None)
+    ap.add_argument("--reads", type=int, default=None, help="c2: reads per GPU per step; c4: reads in the one set")
+    ap.add_argument("--read-len", type=int, default=None)
+    ap.add_argument("--no-c5", action="store_true", help="skip the tandem-repeat build leg (c2, one GPU)")
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -153,6 +351,10 @@ def main():
                     help="seconds the multi-rank sharded build may take before it is reported as stuck")
     ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
     args = ap.parse_args()
+    dflt = {"c2": (46_000_000, 10_000_000, 50), "c4": (3_100_000_000, 100_000_000, 100)}[args.config]
+    args.genome_bp = args.genome_bp or dflt[0]
+    args.reads = args.reads or dflt[1]
+    args.read_len = args.read_len or dflt[2]
 
     if os.environ.get("BWT_BENCH_TRACE_AFTER"):  # debugging aid: dump every thread's stack and exit
         import faulthandler
@@ -183,6 +385,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.config == "c4":
+        return bench_c4(args, rank, world, dist, barrier, red_dev)
 
     # ---- inputs, generated in HBM (same genome on every rank, own reads) ----
     d_text = G.gen_genome(n, synth.GENOME_SEED)
@@ -291,42 +496,63 @@ def main():
     pos, _, locate_s, loc_ms = time_locate()
     located = int((pos != -1).sum().item())
 
+    phase = {"at": "start"}
+
     def sharded_build():
-        """HP1 sharded: one shard of the suffix array per rank, all-gathered into place."""
+        """HP1 sharded: one bucket range of the suffix array sorted per rank; the ranks all-gather
+        the index products of their rows (2-bit BWT symbols + every 8th row), every rank assembles
+        its index.  Timed with and without the second exchange (the rows themselves, for the
+        search-only position records)."""
         try:
-            ixs, how = G.build_index_sharded(d_text, n)  # warm-up (workspace, RCCL channels)
-            ixs.close()
-            barrier()
-            t0 = time.perf_counter()
-            ixs, how = G.build_index_sharded(d_text, n)
-            barrier()
-            ts = time.perf_counter() - t0
-            same = ixs.C == ix.C and ixs.endloc == ix.endloc
-            if same:
-                probe, _ = G.gen_reads(d_text, n, 100000, m, 4242, want_offsets=False)
-                a = ix.search(probe, m, 100000, want_locrow=True)
-                b = ixs.search(probe, m, 100000, want_locrow=True)
-                same = all(torch.equal(x, y) for x, y in zip(a, b))
-            ixs.close()
-            tt = torch.tensor([ts], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_max = float(tt.item())
-            return {"how": how, "wall_ms": t_max * 1e3, "value": n / t_max / 1e6,
-                    "unit": "Mbp/s", "same_as_whole_build": bool(same),
-                    "roofline": {"bound": "hbm", "bytes_per_bp": 5.625, "achieved": 5.625 * n / t_max / 1e9,
-                                 "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
-                                 "frac": 5.625 * n / t_max / 1e9 / (HBM_PEAK_GBS * world)},
-                    "what": "text replicated, one bucket range of the SA sorted per rank, shards all-gathered "
-                            "over RCCL, every rank finishes its own index"}
+            out = {}
+            for key, want_sa in (("index", False), ("index_and_suffix_array", True)):
+                phase["at"] = f"sharded build ({key}) warm-up"
+                ixs, how = G.build_index_sharded(d_text, n, want_sa=want_sa)  # workspace, RCCL channels
+                ixs.close()
+                phase["at"] = f"sharded build ({key}) barrier"
+                barrier()
+                t0 = time.perf_counter()
+                phase["at"] = f"sharded build ({key}) timed run"
+                ixs, how = G.build_index_sharded(d_text, n, want_sa=want_sa)
+                barrier()
+                ts = time.perf_counter() - t0
+                same = ixs.C == ix.C and ixs.endloc == ix.endloc
+                if same:
+                    probe, _ = G.gen_reads(d_text, n, 100000, m, 4242, want_offsets=False)
+                    a = ix.search(probe, m, 100000, want_locrow=True)
+                    b = ixs.search(probe, m, 100000, want_locrow=True)
+                    same = all(torch.equal(x, y) for x, y in zip(a, b))
+                    if want_sa:
+                        rep = ixs.certify(d_text)
+                        same = same and all(v == 0 for v in rep.values())
+                ixs.close()
+                phase["at"] = f"sharded build ({key}) all-reduce of the time"
+                tt = torch.tensor([ts], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_max = float(tt.item())
+                out[key] = {"how": how, "wall_ms": t_max * 1e3, "value": n / t_max / 1e6, "unit": "Mbp/s",
+                            "same_as_whole_build": bool(same),
+                            "roofline": {"bound": "hbm", "bytes_per_bp": 5.625,
+                                         "achieved": 5.625 * n / t_max / 1e9, "peak": HBM_PEAK_GBS * world,
+                                         "unit": "GB/s", "frac": 5.625 * n / t_max / 1e9 / (HBM_PEAK_GBS * world)}}
+            out["what"] = ("text replicated; each rank sorts one bucket range and the ranks all-gather 0.75 B/base "
+                           "of index products over RCCL (index); then 4 B/base of rows for the position records "
+                           "(index_and_suffix_array)")
+            phase["at"] = "done"
+            return out
         except Exception as e:  # noqa: BLE001 - the search figures do not depend on this
-            return {"error": f"{type(e).__name__}: {e}"[:400]}
+            return {"error": f"{type(e).__name__}: {e}"[:400], "phase": phase["at"]}
 
     import threading
     printed = threading.Lock()
 
     if rank != 0:
-        # a collective that never returns must not keep this rank alive for ever
-        dog = threading.Timer(args.sharded_timeout, lambda: os._exit(0))
+        # a collective that never returns must not keep this rank alive for ever; a hang is a failure
+        def stuck():
+            print(f"rank {rank}: no progress for {args.sharded_timeout} s in: {phase['at']}", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(args.sharded_timeout, stuck)
         dog.daemon = True
         dog.start()
         sharded_build()
@@ -346,6 +572,11 @@ def main():
     bpr = (loads["bytes"] - (4 * loads["pattern_words_4B"] if fused else 0)) / R + (m if fused else 0) + 12.0
     achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
     index_bytes = ix.device_bytes
+    traffic = measured_traffic(f"{n}bp_{R}x{m}")
+    try:
+        gather_lines = G.gather_rate(8) if world == 1 else None
+    except Exception:  # noqa: BLE001 - a probe, not a result
+        gather_lines = None
 
     # ---- the callers of the search path, beside the headline: mms, the search_reads anchor loop,
     # align_read_anchored; 10^6 reads of 100 bases, 30 % with two substitutions, 5 % with an N ----
@@ -403,12 +634,20 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic(f"{n}bp_{R}x{m}"),
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_fm_search.json: rocprofv3 --pmc passes of this workload taken by "
+                               "the builder (TCC_EA0_RDREQ/WRREQ families, corrected as the microarchitecture guide "
+                               "says); looked up, not measured in this run") if traffic is not None else None,
             # the kernel is bound by how many cache lines per second leave L2, not by bytes
-            "l2_miss_lines_per_s": (measured_traffic(f"{n}bp_{R}x{m}_l2_misses") or 0) / (k_ms * 1e-3) if k_ms else None,
-            # what plain random 4-byte gathers over 24 GiB reach on this GPU (tools_probe/gather_probe.hip,
-            # profiles/r1_gather_probe.txt): the ceiling for loads with no locality
-            "random_gather_lines_per_s": 46e9,
+            "l2_miss_lines_per_s_from_profiles": (measured_traffic(f"{n}bp_{R}x{m}_l2_misses") or 0) / (k_ms * 1e-3)
+            if k_ms and traffic is not None else None,
+            # plain random 4-byte gathers over 8 GiB, measured in this run (bwtgpu_diag_gather_rate):
+            # the ceiling for loads with no locality
+            "random_gather_lines_per_s": gather_lines,
+            # distinct lines a read asks for, from the counting build: rank blocks, record lines (the
+            # text window and the ISA entry share one), SA entries, table entries
+            "requested_lines_per_read": (loads["rank_blocks_16B"] + loads["text_windows_16B"]
+                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries_8B"]) / R,
             "bytes_per_read": bpr,
             "loads": loads,
             "counting_pass_matches": counted_ok,
@@ -452,6 +691,8 @@ def main():
                 # HBM bytes one build moves over all its kernels (a sort makes several passes), from the
                 # committed PMC passes of this workload
                 "traffic": measured_traffic(f"{n}bp_build"),
+                "traffic_source": "profiles/pmc_fm_search.json (builder's rocprofv3 --pmc passes; looked up, "
+                                  "not measured in this run)",
             },
             "stats": {"levels": sa_stats[0], "leaves": sa_stats[1], "unresolved_rows": sa_stats[2],
                       "doubling_rounds": sa_stats[3]},
@@ -469,6 +710,11 @@ def main():
         "search_kernels_ms": {k: round(v[1] / max(v[0], 1), 4) for k, v in sorted(search_kernels.items())},
         "index_bytes": index_bytes,
     }
+    if world == 1 and not args.no_c5:
+        try:
+            result["c5_repeats"] = c5_leg(args)
+        except Exception as e:  # noqa: BLE001 - the headline does not depend on this
+            result["c5_repeats"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if not args.no_cpu and world == 1:
         gs = G.to_numpy_u32(sp[: args.cpu_reads])
         ge = G.to_numpy_u32(ep[: args.cpu_reads])
@@ -478,9 +724,10 @@ def main():
         # returns, the line goes out without it
         def give_up():
             if printed.acquire(blocking=False):
-                result["sa_build_sharded"] = {"error": f"no result within {args.sharded_timeout} s"}
+                result["sa_build_sharded"] = {"error": f"no result within {args.sharded_timeout} s",
+                                              "stuck_in": phase["at"], "rank": rank}
                 print(json.dumps(result), flush=True)
-                os._exit(0)
+                os._exit(3)  # the line is out, but a hang is not a successful run
 
         dog = threading.Timer(args.sharded_timeout, give_up)
         dog.daemon = True

@@ -63,6 +63,10 @@ SIGNATURES = {
     "bwtgpu_search_static": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bwtgpu_sa_bucket_counts": (C.c_int, [vp, u32, vp, vp]),
     "bwtgpu_sa_build_range": (C.c_int, [vp, u32, u32, u32, vp, vp, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_pack_bw2": (C.c_int, [vp, u64, vp, vp]),
+    "bwtgpu_index_build_from_shards": (vp, [vp, u32, u32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
+                                            vp, vp, vp]),
+    "bwtgpu_index_attach_sa": (C.c_int, [vp, vp, vp, vp]),
     "bwtgpu_index_build_from_sa": (vp, [vp, u32, vp, vp, u32, vp]),
     "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
     "bwtgpu_index_compact": (C.c_int, [vp]),
@@ -76,6 +80,8 @@ SIGNATURES = {
     "bwtgpu_locate_rows": (C.c_int, [vp, vp, u64, vp, vp, vp, sz, vp]),
     "bwtgpu_gen_genome": (C.c_int, [vp, u64, u64, vp]),
     "bwtgpu_gen_reads": (C.c_int, [vp, u64, vp, u64, u32, u64, vp, vp]),
+    "bwtgpu_gen_reads_slice": (C.c_int, [vp, u64, vp, u64, u64, u32, u64, vp, vp]),
+    "bwtgpu_diag_gather_rate": (C.c_int, [vp, u64, u64, C.POINTER(C.c_double), vp]),
     "bwtgpu_diag_scan": (C.c_int, [C.c_int, vp, vp, u64, vp, vp]),
     "bwtgpu_diag_radix_sort": (C.c_int, [vp, vp, u64, C.c_int, vp]),
 }

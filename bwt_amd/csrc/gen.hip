@@ -33,20 +33,23 @@ __global__ void k_gen_genome(uint8_t *__restrict__ text, uint64_t n, uint64_t se
   }
 }
 
+// reads [first, first + R) of the set that `seed` names, written from reads[0] on
 __global__ void k_gen_reads(const uint8_t *__restrict__ text, uint64_t n, uint8_t *__restrict__ reads,
-                            uint64_t R, uint32_t m, uint64_t seed, uint32_t *__restrict__ offsets) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= R) return;
-  uint8_t *out = reads + r * m;
+                            uint64_t first, uint64_t R, uint32_t m, uint64_t seed,
+                            uint32_t *__restrict__ offsets) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R) return;
+  const uint64_t r = first + i;
+  uint8_t *out = reads + i * m;
   const uint64_t words = (m + 31) / 32;
   if (rnd64(seed, 2 * r + 1) % 100 == 0) {
     for (uint32_t k = 0; k < m; ++k)
       out[k] = (uint8_t)((rnd64(seed ^ 0xABCDull, r * words + k / 32) >> (2 * (k % 32))) & 3u);
-    if (offsets) offsets[r] = 0xFFFFFFFFu;
+    if (offsets) offsets[i] = 0xFFFFFFFFu;
   } else {
     const uint64_t j = rnd64(seed, 2 * r) % (n - m + 1);
     for (uint32_t k = 0; k < m; ++k) out[k] = (uint8_t)text_base(text, j + k);
-    if (offsets) offsets[r] = (uint32_t)j;
+    if (offsets) offsets[i] = (uint32_t)j;
   }
 }
 
@@ -65,14 +68,19 @@ int bwtgpu_gen_genome(uint8_t *d_text, uint64_t n, uint64_t seed, void *stream) 
   return kOk;
 }
 
-int bwtgpu_gen_reads(const uint8_t *d_text, uint64_t n, uint8_t *d_reads, uint64_t R, uint32_t m,
-                     uint64_t seed, uint32_t *d_offsets, void *stream) {
+int bwtgpu_gen_reads_slice(const uint8_t *d_text, uint64_t n, uint8_t *d_reads, uint64_t first, uint64_t R,
+                           uint32_t m, uint64_t seed, uint32_t *d_offsets, void *stream) {
   if (!d_text || !d_reads || m == 0 || m > n) return set_error(kErrArg, "bad reads request");
   if (R == 0) return kOk;
   BWT_LAUNCH("gen_reads", k_gen_reads, dim3((unsigned)div_up(R, 256)), dim3(256), 0,
-             (hipStream_t)stream, d_text, n, d_reads, R, m, seed, d_offsets);
+             (hipStream_t)stream, d_text, n, d_reads, first, R, m, seed, d_offsets);
   BWT_CHECK_LAUNCH();
   return kOk;
+}
+
+int bwtgpu_gen_reads(const uint8_t *d_text, uint64_t n, uint8_t *d_reads, uint64_t R, uint32_t m,
+                     uint64_t seed, uint32_t *d_offsets, void *stream) {
+  return bwtgpu_gen_reads_slice(d_text, n, d_reads, 0, R, m, seed, d_offsets, stream);
 }
 
 }  // extern "C"

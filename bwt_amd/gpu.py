@@ -90,6 +90,13 @@ class GpuIndex:
             pass
 
     @property
+    def keeps_suffix_array_by_default(self):
+        """False when the library is told to build compact indexes, or the text is
+        too long for the position records (see bwtgpu_index_attach_sa)."""
+        import os
+        return not os.environ.get("BWT_MI355X_COMPACT") and self.n <= 0xFFFFFF00
+
+    @property
     def device_bytes(self):
         return int(_lib.load().bwtgpu_index_device_bytes(self.h))
 
@@ -273,17 +280,44 @@ def build_index_from_sa(d_text, n, d_sa, d_bw=None, endloc=0):
                                                            _stream()))
 
 
-def build_index_sharded(d_text, n, group=None):
-    """make_fmi with the suffix array sorted in shards, one per rank of `group`
-    (bwt_amd.dist.build_sa_sharded); every rank returns its own copy of the
-    index.  Texts whose shards hold long repeats are built whole on every rank
-    instead.  Returns (index, "sharded" | "whole")."""
+def pack_bw2(d_bw, rows):
+    """BWT symbols one per byte -> four per byte (bwtgpu_pack_bw2)."""
+    out = torch.empty((rows + 3) // 4, dtype=torch.uint8, device="cuda")
+    check(_lib.load().bwtgpu_pack_bw2(_ptr(d_bw), rows, _ptr(out), _stream()))
+    return out
+
+
+def build_index_from_shards(d_text, n, parts):
+    """make_fmi's index from what every shard contributed (bwt_amd.dist.ShardedParts)."""
+    k = len(parts.rows_of)
+    begin = (C.c_uint64 * k)(*[b for b, _ in parts.rows_of])
+    rows = (C.c_uint64 * k)(*[r for _, r in parts.rows_of])
+    offs = (C.c_uint64 * k)(*parts.bw2_offsets)
+    return GpuIndex(_lib.load().bwtgpu_index_build_from_shards(_ptr(d_text), n, parts.endloc, k, begin, rows, offs,
+                                                               _ptr(parts.bw2), _ptr(parts.samples), _stream()))
+
+
+def build_index_sharded(d_text, n, group=None, want_sa=True):
+    """make_fmi with the suffix array sorted in shards, one per rank of `group`:
+    each rank sorts its bucket range, the ranks all-gather the index products of
+    their rows (2-bit BWT symbols + every 8th row, 0.75 bytes per base:
+    bwt_amd.dist.build_index_parts_sharded) and every rank assembles its own
+    copy of the index.  With want_sa the rows themselves (4 bytes per base) are
+    all-gathered afterwards and attached, so that searches get the position
+    records as on an index built whole.  Texts whose shards hold long repeats are
+    built whole on every rank instead.  Returns (index, "sharded" | "whole")."""
+    import torch.distributed as tdist
+
     from . import dist as D
 
+    world = tdist.get_world_size(group)
+    rank = tdist.get_rank(group)
     counts = sa_bucket_counts(d_text, n)
+    ranges = D.plan_bucket_ranges(counts, world)
+    mine = D.shard_rows(counts, ranges)[rank][1]
     ws = torch.empty(int(_lib.load().bwtgpu_sa_workspace_bytes(n)), dtype=torch.uint8, device="cuda")
-    sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
-    bw = torch.empty(n + 1, dtype=torch.uint8, device="cuda")
+    rows_buf = torch.empty(max(mine, 1), dtype=torch.int32, device="cuda")
+    bw_buf = torch.empty(max(mine, 1), dtype=torch.uint8, device="cuda")
 
     def build_range(lo, hi, rows_out, bw_out):
         try:
@@ -294,12 +328,17 @@ def build_index_sharded(d_text, n, group=None):
             raise
 
     try:
-        endloc = D.build_sa_sharded(n, counts, build_range, sa, bw, group)
+        parts = D.build_index_parts_sharded(n, counts, build_range, pack_bw2, rows_buf, bw_buf, group)
     except D.NeedsWholeText:
-        del sa, bw, ws
+        del rows_buf, bw_buf, ws
         return build_index_dev(d_text, n), "whole"
-    del ws
-    return build_index_from_sa(d_text, n, sa, bw[1:], endloc), "sharded"
+    del ws, bw_buf
+    ix = build_index_from_shards(d_text, n, parts)
+    if want_sa and ix.keeps_suffix_array_by_default:
+        sa = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        D.gather_suffix_array(n, parts.rows_of, rows_buf, sa, group)
+        check(_lib.load().bwtgpu_index_attach_sa(ix.h, _ptr(d_text), _ptr(sa), _stream()))
+    return ix, "sharded"
 
 
 def dp_align_batch(d_s1, d_off1, d_s2, d_off2, R, mode, max_len1, max_len2):
@@ -347,9 +386,20 @@ def gen_genome(n, seed):
     return t
 
 
-def gen_reads(d_text, n, R, m, seed, want_offsets=True):
+def gen_reads(d_text, n, R, m, seed, want_offsets=True, first=0):
+    """Reads [first, first + R) of the read set `seed` names (1 % random, the rest
+    cut from the text at the offsets returned)."""
     lib = _lib.load()
     reads = torch.empty(R * m + 64, dtype=torch.uint8, device="cuda")
     offs = torch.empty(R, dtype=torch.int32, device="cuda") if want_offsets else None
-    check(lib.bwtgpu_gen_reads(_ptr(d_text), n, _ptr(reads), R, m, seed, _ptr(offs), _stream()))
+    check(lib.bwtgpu_gen_reads_slice(_ptr(d_text), n, _ptr(reads), first, R, m, seed, _ptr(offs), _stream()))
     return reads, offs
+
+
+def gather_rate(gib=4, loads=1 << 28):
+    """Random 64-byte lines per second over a buffer of `gib` GiB (bwtgpu_diag_gather_rate)."""
+    buf = torch.ones(int(gib * (1 << 30)) // 4, dtype=torch.int32, device="cuda")
+    out = C.c_double()
+    check(_lib.load().bwtgpu_diag_gather_rate(_ptr(buf), buf.numel() * 4, loads, C.byref(out), _stream()))
+    del buf
+    return float(out.value)

@@ -78,6 +78,30 @@ int bwtgpu_sa_build_range(const uint8_t *d_text, uint32_t n, uint32_t bucket_lo,
                           uint64_t capacity, uint64_t *row_begin, uint64_t *rows,
                           uint32_t *endloc, void *d_ws, size_t ws_bytes, void *stream);
 
+/* What the ranks of a sharded build exchange is not the rows but what the index
+ * needs of them: the BWT symbol of every row packed to 2 bits and every 8th row
+ * (0.75 bytes per base instead of 5).
+ * bwtgpu_pack_bw2: d_bw[0 .. rows) (one symbol per byte, as bwtgpu_sa_build_range
+ * leaves them) -> (rows+3)/4 bytes, symbol j at bits 2 (j & 3) of byte j >> 2.
+ * bwtgpu_index_build_from_shards: the index of make_fmi (seqindex.c:161-189)
+ * from every shard's packed symbols: shard g holds rows [h_row_begin[g],
+ * h_row_begin[g] + h_rows[g]) -- the shards cover rows 1..n in order -- and its
+ * symbols start at byte h_bw2_offset[g] of d_bw2; d_samples[i] = SA[8 i] for i in
+ * [0, n/8] (d_samples[0] = n); endloc = the row of suffix 0.  At most 64 shards.
+ * The index keeps no suffix array (it searches on rank blocks and the k-mer
+ * table) until bwtgpu_index_attach_sa hands it the n+1 assembled rows, which it
+ * copies and from which the first search then makes the position records.
+ * No counterpart in the reference, whose threads share one address space
+ * (histsortcomp.c:112-158). */
+int bwtgpu_pack_bw2(const uint8_t *d_bw, uint64_t rows, uint8_t *d_out, void *stream);
+bwtgpu_index *bwtgpu_index_build_from_shards(const uint8_t *d_text, uint32_t n, uint32_t endloc,
+                                             uint32_t nshards, const uint64_t *h_row_begin,
+                                             const uint64_t *h_rows, const uint64_t *h_bw2_offset,
+                                             const uint8_t *d_bw2, const uint32_t *d_samples,
+                                             void *stream);
+int bwtgpu_index_attach_sa(bwtgpu_index *ix, const uint8_t *d_text, const uint32_t *d_sa,
+                           void *stream);
+
 /* Replaces sprintcbwt (histsortcomp.c:220-250): packed BWT without the $ row
  * ((n+3)/4 bytes at d_bwt) and the $ row number at *d_endloc. */
 int bwtgpu_bwt_from_sa(const uint8_t *d_text, const uint32_t *d_sa, uint32_t n,
@@ -332,7 +356,19 @@ int bwtgpu_gen_reads(const uint8_t *d_text, uint64_t n, uint8_t *d_reads,
                      uint64_t R, uint32_t m, uint64_t seed, uint32_t *d_offsets,
                      void *stream);
 
+/* reads [first, first + R) of the set of reads `seed` names, so that ranks can
+ * each generate their slice of ONE set; bwtgpu_gen_reads is first = 0 */
+int bwtgpu_gen_reads_slice(const uint8_t *d_text, uint64_t n, uint8_t *d_reads, uint64_t first,
+                           uint64_t R, uint32_t m, uint64_t seed, uint32_t *d_offsets,
+                           void *stream);
+
 /* ---- diagnostics: drive internal device primitives from the tests ---- */
+/* Rate of random 4-byte loads (one 64-byte line each) over d_buf[0 .. bytes),
+ * the ceiling for loads without locality: `loads` of them, timed with HIP events
+ * on `stream`, best of three launches.  The last 4 bytes of the buffer are a
+ * sink.  No counterpart in the reference. */
+int bwtgpu_diag_gather_rate(const void *d_buf, uint64_t bytes, uint64_t loads,
+                            double *lines_per_s, void *stream);
 /* No counterpart in the reference.  op 0: exclusive add scan, 1: inclusive
  * max scan, over uint32; allocate their own scratch and synchronise. */
 int bwtgpu_diag_scan(int op, const uint32_t *d_in, uint32_t *d_out, uint64_t count,

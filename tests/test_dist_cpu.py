@@ -18,6 +18,15 @@ from bwt_amd import dist as D  # noqa: E402
 from bwt_amd import synth  # noqa: E402
 
 
+def test_sample_span_lists_every_eighth_row():
+    for begin, rows in ((1, 0), (1, 5), (1, 7), (1, 8), (8, 1), (9, 7), (9, 8), (16, 17), (12345, 1000)):
+        first, i0, cnt = D.sample_span(begin, rows)
+        want = [r for r in range(begin, begin + rows) if r % 8 == 0]
+        assert cnt == len(want)
+        if want:
+            assert begin + first == want[0] and i0 == want[0] // 8
+
+
 def test_slice_bounds_cover_everything_once():
     for total in (0, 1, 7, 100, 10_000_001):
         for world in (1, 2, 3, 8):
@@ -101,6 +110,26 @@ def _worker(rank, world, port, n, R, m, fail_rank, q, skewed=False):
         assert endloc == endloc_o
         np.testing.assert_array_equal(sa.numpy().view(np.uint32), sa_o)
         np.testing.assert_array_equal(bw.numpy()[1:], bw_o[1:])
+
+        # the index-products exchange: 2-bit symbols and every 8th row of each rank's own rows
+        def pack_bw2(bw_t, rows):
+            b = np.concatenate([bw_t.numpy()[:rows], np.zeros((-rows) % 4, np.uint8)]).reshape(-1, 4)
+            return torch.from_numpy((b[:, 0] | (b[:, 1] << 2) | (b[:, 2] << 4) | (b[:, 3] << 6)).astype(np.uint8))
+
+        mine = D.shard_rows(counts, D.plan_bucket_ranges(counts, world))[rank][1]
+        rows_buf = torch.full((max(mine, 1),), -7, dtype=torch.int32)
+        bw_buf = torch.zeros(max(mine, 1), dtype=torch.uint8)
+        parts = D.build_index_parts_sharded(n, counts, build_range, pack_bw2, rows_buf, bw_buf)
+        assert parts.endloc == endloc_o
+        np.testing.assert_array_equal(parts.samples.numpy().view(np.uint32), sa_o[::8])
+        packed = parts.bw2.numpy()
+        for g, (b, r) in enumerate(parts.rows_of):
+            j = np.arange(r)
+            sym = (packed[parts.bw2_offsets[g] + (j >> 2)] >> (2 * (j & 3))) & 3
+            np.testing.assert_array_equal(sym, bw_o[b:b + r])
+        sa2 = torch.full((n + 1,), -7, dtype=torch.int32)
+        D.gather_suffix_array(n, parts.rows_of, rows_buf, sa2)
+        np.testing.assert_array_equal(sa2.numpy().view(np.uint32), sa_o)
 
         # reads: every rank searches its slice with the oracle; rank 0 gets them all in order
         fo = orc.make_fmi(text, n, sa_o)

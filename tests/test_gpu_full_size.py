@@ -27,6 +27,9 @@ def test_headline_configuration_at_full_size(oracle, gpu):
 
     # the index: what make_fmi (seqindex.c:161-189) derives from that suffix array
     ix = gpu.build_index_dev(d_text, N)
+    rep = ix.certify(d_text)  # the device's own certificate agrees with the host's
+    assert all(v == 0 for v in rep.values()), rep
+    assert gpu.sa_certify(d_text, N, sa) == (0, 0, 0)
     fo = oracle.make_fmi(text, N, sa_h)
     assert ix.endloc == fo.endloc and ix.C == fo.C
     bwt, idxs = ix.export()
@@ -128,17 +131,23 @@ def test_100_mbp_tandem_repeat_suffix_array(oracle, gpu, period, mutations):
 
 
 def test_3100_mbp_index_and_search(gpu):
-    """3.1 Gbp, beyond the reference's `int` lengths: no CPU answer exists, so
-    the checks are the ones the text itself provides -- C[4] = n + 1, every read
-    cut from the text found, every unique one located at the offset it was cut
-    at -- and the two search forms (text comparison, rank queries only) against
-    each other."""
-    n, R, m = 3_100_000_000, 20_000_000, 100
+    """3.1 Gbp with 100 M x 100 bp reads, beyond the reference's `int` lengths: no
+    CPU answer exists, so the checks are the O(n) certificate of the suffix
+    array, BWT and samples computed on the device, what the text itself
+    provides -- C[4] = n + 1, every read cut from the text found, every unique one
+    located at the offset it was cut at -- and the two search forms (text
+    comparison, rank queries only) against each other."""
+    n, R, m = 3_100_000_000, 100_000_000, 100
     d_text = gpu.gen_genome(n, synth.GENOME_SEED)
     ix = gpu.build_index_dev(d_text, n)
     stats = gpu.sa_last_stats()
     assert ix.C[0] == 1 and ix.C[4] == n + 1 and 0 < ix.endloc <= n
     assert stats[2] == 0 and stats[3] == 0
+    # the certificate computed on the device: the suffix array the index keeps is the suffix
+    # array of this text (permutation + order of all 3.1 G neighbouring rows), and every BWT
+    # block, every sampled row and the $ row follow from it
+    rep = ix.certify(d_text)
+    assert all(v == 0 for v in rep.values()), rep
     reads, offs = gpu.gen_reads(d_text, n, R, m, synth.READS_SEED)
     sp, ep, lr = ix.search(reads, m, R, want_locrow=True)
     pos = ix.locate_rows(lr)
