@@ -51,6 +51,7 @@ SIGNATURES = {
     "bwtgpu_search_reads_host": (C.c_int, [vp, vp, vp, u64, C.c_int, vp]),
     "bwtgpu_occ_batch": (C.c_int, [vp, vp, vp, u64, C.c_int, vp, vp]),
     "bwtgpu_lf_batch": (C.c_int, [vp, vp, u64, vp, vp]),
+    "bwtgpu_sort_suffixes_host": (C.c_int, [vp, u32, vp, u64]),
     "bwtgpu_sa_build_host": (C.c_int, [vp, u32, vp]),
     "bwtgpu_bwt_from_sa_host": (C.c_int, [vp, vp, u32, vp, vp]),
     "bwtgpu_reverse_search_host": (C.c_int, [vp, vp, u32, u64, u64, vp]),

@@ -6,6 +6,7 @@
 #include "common.hpp"
 #include "fm_device.hpp"
 #include "mms_device.hpp"
+#include "radix_sort.hpp"
 
 namespace bwtgpu {
 
@@ -100,11 +101,62 @@ __global__ void k_reverse_result(uint32_t *__restrict__ sp, const uint32_t *__re
   sp[r] = locrow[r] == 0xFFFFFFFFu ? 0u : ep[r] - sp[r] + 1u;
 }
 
+// rank[sa[r]] = r: the row of every suffix
+__global__ void k_rows_of_suffixes(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t *__restrict__ rank) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) rank[sa[r]] = (uint32_t)r;
+}
+
+// sort key of every id handed in: its row in the suffix array
+__global__ void k_keys_of_ids(const uint32_t *__restrict__ ids, uint64_t count, uint32_t n,
+                              const uint32_t *__restrict__ rank, uint64_t *__restrict__ keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) keys[i] = ids[i] <= n ? rank[ids[i]] : 0xFFFFFFFFull;
+}
+
 }  // namespace bwtgpu
 
 using namespace bwtgpu;
 
 extern "C" {
+
+// histhelper (histsortcomp.c:35-90) sorts a run of suffix starts that agree on
+// their first `depth` bases by what follows.  Whatever the depth, that is the
+// order the suffixes have in the suffix array of the whole text, so the device
+// builds that array, turns it into the row of every suffix and sorts the ids
+// handed in by their rows.  An id equal to n is the empty suffix and comes
+// first; ids above n go last.
+int bwtgpu_sort_suffixes_host(const uint8_t *h_text, uint32_t n, uint32_t *h_ids, uint64_t count) {
+  if (!h_text || !h_ids || n == 0) return set_error(kErrArg, "bad argument");
+  if (count <= 1) return kOk;
+  if (count >= (1ull << 32)) return set_error(kErrArg, "too many suffixes");
+  Dev text, sa, ws, rank, keys, keys_alt, ids, ids_alt, sws;
+  const size_t nbytes = (size_t)n / 4 + 1, wsb = bwtgpu_sa_workspace_bytes(n), rows = (size_t)n + 1;
+  const size_t swsb = radix_sort_workspace_bytes(count);
+  hipError_t e = text.alloc(nbytes + 64);
+  if (e == hipSuccess) e = sa.alloc(rows * 4);
+  if (e == hipSuccess) e = ws.alloc(wsb);
+  if (e == hipSuccess) e = rank.alloc(rows * 4);
+  if (e == hipSuccess) e = keys.alloc(count * 8);
+  if (e == hipSuccess) e = keys_alt.alloc(count * 8);
+  if (e == hipSuccess) e = ids.alloc(count * 4);
+  if (e == hipSuccess) e = ids_alt.alloc(count * 4);
+  if (e == hipSuccess) e = sws.alloc(swsb);
+  if (e != hipSuccess) return set_error(kErrHip, "buffers to sort %llu suffixes of %u bases: %s",
+                                        (unsigned long long)count, n, hipGetErrorString(e));
+  BWT_HIP(hipMemcpy(text.p, h_text, nbytes, hipMemcpyHostToDevice));
+  BWT_HIP(hipMemcpy(ids.p, h_ids, count * 4, hipMemcpyHostToDevice));
+  BWT_TRY(bwtgpu_sa_build(text.as<uint8_t>(), n, sa.as<uint32_t>(), ws.p, wsb, nullptr));
+  BWT_LAUNCH("rows_of_suffixes", k_rows_of_suffixes, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, nullptr,
+             sa.as<uint32_t>(), (uint64_t)rows, rank.as<uint32_t>());
+  BWT_LAUNCH("keys_of_ids", k_keys_of_ids, dim3((unsigned)div_up(count, 256)), dim3(256), 0, nullptr,
+             ids.as<uint32_t>(), count, n, rank.as<uint32_t>(), keys.as<uint64_t>());
+  BWT_CHECK_LAUNCH();
+  BWT_TRY(radix_sort_pairs(keys.as<uint64_t>(), ids.as<uint32_t>(), keys_alt.as<uint64_t>(), ids_alt.as<uint32_t>(),
+                           count, 32, sws.p, swsb, nullptr));
+  BWT_HIP(hipMemcpy(h_ids, ids.p, count * 4, hipMemcpyDeviceToHost));
+  return kOk;
+}
 
 int bwtgpu_occ_batch(const bwtgpu_index *ix, const uint8_t *d_c, const uint32_t *d_idx, uint64_t R,
                      int skip_dollar_row, uint32_t *d_out, void *stream) {

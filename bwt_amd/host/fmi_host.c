@@ -1,9 +1,24 @@
 /*
  * The reference's C API (histsortcomp.h, csacak.h, seqindex.h, fileio.h) over
- * the HIP kernels of libbwt_mi355x.so.  Every function here hands its work to
- * a device entry point of bwt_gpu.h; there is no host implementation of the
- * algorithms to fall back on.  When the device call fails the error goes to
- * stderr and the function returns the reference's failure value.
+ * the HIP kernels of libbwt_mi355x.so.
+ *
+ * Everything that is a batch of work -- building a suffix array, a BWT, an
+ * index, loading one, and every fmi_*_batch call -- is handed to a device entry
+ * point of bwt_gpu.h; there is no host implementation of those to fall back on,
+ * and when the device call fails the error goes to stderr and the function
+ * returns the reference's failure value.
+ *
+ * The reference's single-query functions (rank, lf, unc_sa, loc_search,
+ * reverse_search, locate, mms) answer ONE query per call: a few hundred
+ * nanoseconds of work on arrays the fm_index already holds on the host (bwt,
+ * idxs, rank_index), against 5-17 microseconds for a kernel launch and a
+ * synchronisation.  They are computed on the host from those arrays (the part
+ * of this file headed "single queries"), so that a caller that loops over them
+ * -- the reference's own fmitest.c:54-65, searchtest.c:71-89 -- is not slowed
+ * down by the library.  BWT_MI355X_SCALAR=device sends them to the GPU as
+ * batches of one instead (the tests compare the two), and so does an fm_index
+ * that lacks the host rank table (len >= 2^28).  Callers that want throughput
+ * use the batch forms.
  */
 #include <pthread.h>
 #include <stdint.h>
@@ -96,6 +111,25 @@ static uint32_t *sa_on_device(const char *str, uint32_t len) {
 int *histsort(const char *str, int len) { return (int *)sa_on_device(str, (uint32_t)len); }
 
 unsigned int *csuff_arr(const char *seq, unsigned int len) { return sa_on_device(seq, len); }
+
+void histhelper(const char *base, int len, int *arr, int *aux, int start, int end, int depth) {
+  /* histsortcomp.c:35-90: arr[start .. end) are starts of suffixes that agree on
+   * their first `depth` bases; sorts them by what follows.  The reference leaves
+   * the result in whichever of the two arrays its file-static `saux` is not
+   * (histsortcomp.c:25, :45-50), which only histsort itself can know; here both
+   * hold it.  `len` is the number of bases, as histsort passes it (:171). */
+  (void)depth;
+  if (end - start <= 0) return;
+  if (end - start > 1) {
+    if (device_ready()) return;
+    if (bwtgpu_sort_suffixes_host((const uint8_t *)base, (uint32_t)len, (uint32_t *)arr + start,
+                                  (uint64_t)(end - start))) {
+      report("histhelper");
+      return;
+    }
+  }
+  if (aux) memcpy(aux + start, arr + start, (size_t)(end - start) * sizeof *arr);
+}
 
 unsigned int sprintcbwt(const char *str, unsigned int *idxs, unsigned int len, char *out) {
   uint32_t endloc = 0xFFFFFFFFu;
@@ -360,10 +394,152 @@ fm_index *read_index(const char *seq, FILE *f) {
 }
 
 /* ------------------------------------------------------------------ */
-/* queries (seqindex.h): single calls are batches of one               */
+/* single queries (seqindex.h): on the host, from the arrays of fm_index */
 /* ------------------------------------------------------------------ */
 
+/* One query per call is latency, not throughput: see the head of this file. */
+static int scalars_on_host(const fm_index *fmi) {
+  if (!fmi || !fmi->bwt || !fmi->idxs || !fmi->rank_index) return 0;
+  const char *env = getenv("BWT_MI355X_SCALAR");
+  return !(env && env[0] == 'd');
+}
+
+/* How many of the first k (0..16) bases of a 16-base group are c.  w holds the
+ * group as the packed text does, first base in the top two bits. */
+static inline unsigned count_in_group(uint32_t w, unsigned c, unsigned k) {
+  uint32_t x = w ^ (c * 0x55555555u);        /* a base equal to c becomes 00 */
+  uint32_t hit = ~(x | (x >> 1)) & 0x55555555u; /* one bit per matching base */
+  if (k < 16) hit &= ~(0xFFFFFFFFu >> (2 * k)); /* keep the first k bases */
+  return (unsigned)__builtin_popcount(hit);
+}
+
+static inline uint32_t group_at(const unsigned char *bwt, uint32_t first_base, uint32_t nbases) {
+  /* the four bytes that hold bases first_base .. first_base + 15, zero past the end of the BWT */
+  const size_t nbytes = ((size_t)nbases + 3) / 4, at = first_base / 4;
+  uint32_t w = 0;
+  for (unsigned k = 0; k < 4; ++k) w = (w << 8) | (at + k < nbytes ? bwt[at + k] : 0u);
+  return w;
+}
+
+/* C-less Occ(c, j): occurrences of c among BWT bases [0, j), j in [0, len]: the row
+ * of the 16-base block (seq_index layout, seqindex.c:23-87) plus a popcount over
+ * what lies between the block's start and j */
+static inline uint32_t host_occ(const fm_index *f, unsigned c, uint32_t j) {
+  const uint32_t blk = j / 16;
+  uint32_t x = (uint32_t)f->rank_index[blk][c];
+  const unsigned k = j % 16;
+  if (k) x += count_in_group(group_at((const unsigned char *)f->bwt, blk * 16, (uint32_t)f->len), c, k);
+  return x;
+}
+
+static inline int host_rank(const fm_index *f, unsigned c, uint32_t idx) {
+  /* seqindex.c:221-225: rows past the unstored $ row sit one place earlier in the BWT */
+  const uint32_t n = (uint32_t)f->len;
+  if (idx > (uint32_t)f->endloc) --idx;
+  if (idx > n) return -1;
+  return (int)host_occ(f, c & 3u, idx);
+}
+
+static inline int host_lf(const fm_index *f, uint32_t idx) {
+  /* seqindex.c:214-219 */
+  const uint32_t n = (uint32_t)f->len;
+  if (idx > n) return -1;
+  if (idx == (uint32_t)f->endloc) return 0;
+  const uint32_t j = idx - (idx > (uint32_t)f->endloc);
+  const unsigned c = base_at(f->bwt, (long)j);
+  return (int)((uint32_t)f->C[c] + host_occ(f, c, j));
+}
+
+static int host_unc_sa(const fm_index *f, uint32_t idx) {
+  /* seqindex.c:244-255: walk LF to the next stored row (every 32nd).  A walk on a
+   * sound index ends within 31 steps; the bound keeps a damaged one from spinning. */
+  const uint32_t n = (uint32_t)f->len;
+  if (idx > n) return -1;
+  uint32_t steps = 0;
+  while (idx & 31u) {
+    const int nxt = host_lf(f, idx);
+    if (nxt < 0 || ++steps > n) return -1;
+    idx = (uint32_t)nxt;
+  }
+  uint64_t x = (uint64_t)(uint32_t)f->idxs[idx / 32] + steps;
+  if (x > n) x -= (uint64_t)n + 1;
+  return (int)(uint32_t)x;
+}
+
+/* the loop of loc_search (seqindex.c:280-309); returns 1 when the interval emptied
+ * before the last step */
+static int host_interval(const fm_index *f, const char *pattern, int len, uint32_t *sp_out, uint32_t *ep_out) {
+  unsigned c = (unsigned char)pattern[len - 1] & 3u;
+  uint32_t sp = (uint32_t)f->C[c], ep = (uint32_t)f->C[c + 1];
+  int early = 0;
+  for (int i = len - 2; i >= 0; --i) {
+    if (ep <= sp) {
+      early = 1;
+      break;
+    }
+    c = (unsigned char)pattern[i] & 3u;
+    sp = (uint32_t)f->C[c] + (uint32_t)host_rank(f, c, sp);
+    ep = (uint32_t)f->C[c] + (uint32_t)host_rank(f, c, ep);
+  }
+  *sp_out = sp;
+  *ep_out = ep;
+  return early;
+}
+
+static int host_mms(const fm_index *f, const char *pattern, int len, int *sp_out, int *ep_out) {
+  /* seqindex.c:314-351: 5 is N.  Trailing Ns are skipped (:317-320); an inner N
+   * is read as the base with the most occurrences in the current interval, the
+   * lowest base on ties (:330-340).  A pattern of Ns only returns its length
+   * and an empty interval (the reference reads before the buffer there). */
+  int skips = 0;
+  while (len > 0 && pattern[len - 1] == 5) {
+    --len;
+    ++skips;
+  }
+  if (len == 0) {
+    *sp_out = 0;
+    *ep_out = 0;
+    return skips;
+  }
+  unsigned c = (unsigned char)pattern[len - 1] & 3u;
+  uint32_t start = (uint32_t)f->C[c], end = (uint32_t)f->C[c + 1], sp = start, ep = end;
+  int i = len - 2;
+  for (; i >= 0; --i) {
+    if (end <= start) break;
+    sp = start;
+    ep = end;
+    if (pattern[i] == 5) {
+      int64_t best = -1;
+      uint32_t bs = 0, be = 0;
+      for (unsigned d = 0; d < 4; ++d) {
+        const uint32_t a = (uint32_t)f->C[d] + (uint32_t)host_rank(f, d, start);
+        const uint32_t b = (uint32_t)f->C[d] + (uint32_t)host_rank(f, d, end);
+        if ((int64_t)b - (int64_t)a > best) {
+          best = (int64_t)b - (int64_t)a;
+          bs = a;
+          be = b;
+        }
+      }
+      start = bs;
+      end = be;
+    } else {
+      c = (unsigned char)pattern[i] & 3u;
+      start = (uint32_t)f->C[c] + (uint32_t)host_rank(f, c, start);
+      end = (uint32_t)f->C[c] + (uint32_t)host_rank(f, c, end);
+    }
+  }
+  if (end <= start) {
+    *sp_out = (int)sp;
+    *ep_out = (int)ep;
+    return len - i - 2 + skips;
+  }
+  *sp_out = (int)start;
+  *ep_out = (int)end;
+  return len - i - 1 + skips;
+}
+
 int rank(const fm_index *fmi, char c, int idx) {
+  if (scalars_on_host(fmi)) return host_rank(fmi, (unsigned char)c, (uint32_t)idx);
   bwtgpu_index *ix = device_index(fmi);
   uint8_t cc = (uint8_t)c;
   uint32_t i = (uint32_t)idx, out = 0;
@@ -375,6 +551,7 @@ int rank(const fm_index *fmi, char c, int idx) {
 }
 
 int lf(const fm_index *fmi, int idx) {
+  if (scalars_on_host(fmi)) return host_lf(fmi, (uint32_t)idx);
   bwtgpu_index *ix = device_index(fmi);
   uint32_t i = (uint32_t)idx, out = 0;
   if (!ix || bwtgpu_lf_host(ix, &i, 1, &out)) {
@@ -385,22 +562,41 @@ int lf(const fm_index *fmi, int idx) {
 }
 
 int unc_sa(const fm_index *fmi, int idx) {
+  if (scalars_on_host(fmi)) return host_unc_sa(fmi, (uint32_t)idx);
   int pos = -1;
   fmi_unc_sa_batch(fmi, &idx, 1, &pos);
   return pos;
 }
 
 void loc_search(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep) {
+  if (len > 0 && scalars_on_host(fmi)) {
+    uint32_t s, e;
+    host_interval(fmi, pattern, len, &s, &e);
+    *sp = (int)s;
+    *ep = (int)e;
+    return;
+  }
   fmi_search_batch(fmi, pattern, len, len, 1, sp, ep);
 }
 
 int reverse_search(const fm_index *fmi, const char *pattern, int len) {
+  if (len > 0 && scalars_on_host(fmi)) {
+    /* seqindex.c:228-242: 0 if the interval emptied before the last step, else ep - sp + 1 (sic) */
+    uint32_t s, e;
+    return host_interval(fmi, pattern, len, &s, &e) ? 0 : (int)(e - s + 1u);
+  }
   int r = 0;
   fmi_reverse_search_batch(fmi, pattern, len, len, 1, &r);
   return r;
 }
 
 int locate(const fm_index *fmi, const char *pattern, int len) {
+  if (len > 0 && scalars_on_host(fmi)) {
+    uint32_t s, e;
+    if (host_interval(fmi, pattern, len, &s, &e)) return -1; /* seqindex.c:268-270 */
+    if (e - s != 1) printf("Warning: multiple matches found (returned first)\n"); /* seqindex.c:274-275 */
+    return host_unc_sa(fmi, s); /* -1 for s = len + 1, where the reference reads out of bounds */
+  }
   bwtgpu_index *ix = device_index(fmi);
   uint32_t sp, ep, row, pos;
   if (!ix || bwtgpu_search_host(ix, (const uint8_t *)pattern, (uint32_t)len, (uint64_t)len, 1, &sp, &ep,
@@ -477,6 +673,7 @@ int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, l
 }
 
 int mms(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep) {
+  if (len > 0 && scalars_on_host(fmi)) return host_mms(fmi, pattern, len, sp, ep);
   int matched = 0;
   if (fmi_mms_batch(fmi, pattern, len, len, 1, &matched, sp, ep)) return 0;
   return matched;

@@ -319,6 +319,12 @@ int bwtgpu_lf_batch(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t R,
 /* histsort / csuff_arr with the reference's own calling convention
  * (histsortcomp.c:161, csacak.c:521): host text in, n+1 host rows out. */
 int bwtgpu_sa_build_host(const uint8_t *h_text, uint32_t n, uint32_t *h_sa);
+/* histhelper (histsortcomp.c:35-90) on host arrays: sorts h_ids[0 .. count), starts
+ * of suffixes of the packed text (an id equal to n is the empty suffix), into
+ * the order those suffixes have in the suffix array.  For a run of suffixes that
+ * agree on their first `depth` bases that is the reference's result at any
+ * depth.  Builds the whole suffix array on the device to do so. */
+int bwtgpu_sort_suffixes_host(const uint8_t *h_text, uint32_t n, uint32_t *h_ids, uint64_t count);
 /* sprintcbwt (histsortcomp.c:220-250) on host arrays. */
 int bwtgpu_bwt_from_sa_host(const uint8_t *h_text, const uint32_t *h_sa, uint32_t n,
                             uint8_t *h_bwt, uint32_t *endloc);

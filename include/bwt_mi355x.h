@@ -6,10 +6,15 @@
  * resolved at link time (reference Makefile:32-60).  This header declares
  * those symbols with the reference's own names, argument order and ownership
  * rules, so that a caller of histsortcomp.o + csacak.o + seqindex.o + fileio.o
- * can link libbwt_mi355x.so instead.  Every one of them runs its work on the
- * MI355X through the device entry points of bwt_gpu.h; none has a CPU path.
- * If no gfx950 device is usable they print the error to stderr and return the
- * reference's failure value (NULL / -1 / 0), as the comments say.
+ * can link libbwt_mi355x.so instead.  Everything that is a batch of work --
+ * suffix array, BWT, index build and load, the batch forms -- runs on the MI355X
+ * through the device entry points of bwt_gpu.h and has no CPU path: if no gfx950
+ * device is usable it prints the error to stderr and returns the reference's
+ * failure value (NULL / -1 / 0), as the comments say.  The single-query
+ * functions (rank, lf, unc_sa, loc_search, reverse_search, locate, mms) answer
+ * one query from the host arrays of the fm_index they are given, because one
+ * query is a fraction of a kernel launch; BWT_MI355X_SCALAR=device sends them to
+ * the GPU as batches of one, as does an fm_index without rank_index.
  *
  * The batch forms at the end have no counterpart in the reference: its
  * callers loop over reads on the host (fmitest.c:54-65, search_reads.c:102-162)
@@ -39,6 +44,12 @@ typedef struct _fmi {
 } fm_index;
 
 /* ---- histsortcomp.h:4-20 ---- */
+/* histsortcomp.h:4 / histsortcomp.c:35-90: sorts arr[start .. end), starts of
+ * suffixes that agree on their first `depth` bases, by what follows; len = the
+ * number of bases.  On return arr[start .. end) and aux[start .. end) both hold
+ * the sorted run (the reference leaves it in one of the two, chosen by a
+ * file-static only histsort sets). */
+void histhelper(const char *base, int len, int *arr, int *aux, int start, int end, int depth);
 /* histsortcomp.h:6 / histsortcomp.c:161-180.  malloc'd (len+1) ints, caller frees. */
 int *histsort(const char *str, int len);
 /* histsortcomp.h:20 / histsortcomp.c:220-250.  out holds (len+3)/4 bytes; returns the $ row. */

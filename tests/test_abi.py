@@ -54,6 +54,17 @@ def test_no_cpu_fallback_without_a_device():
     hl = ctypes.CDLL(_lib.LIB_PATH)
     hl.make_fmi.restype = ctypes.c_void_p
     assert hl.make_fmi(ctypes.create_string_buffer(8), 16) is None
+    hl.histsort.restype = ctypes.c_void_p
+    assert hl.histsort(ctypes.create_string_buffer(8), 16) is None
+    # ... and so do the batch forms, even on an fm_index whose host arrays would answer single queries
+    from test_host_scalars import host_fm_index
+    from oracle import load_oracle
+    orc = load_oracle()
+    n = 500
+    fo = orc.make_fmi(orc.gen_genome(n, 1), n)
+    f, keep = host_fm_index(fo, n)
+    sp, ep = (ctypes.c_int * 4)(), (ctypes.c_int * 4)()
+    assert hl.fmi_search_batch(ctypes.byref(f), ctypes.create_string_buffer(64), 8, 8, 4, sp, ep) == -1
 
 
 def test_host_packer_matches_build_index(oracle):

@@ -245,3 +245,98 @@ def test_fmitest_driver_runs(tmp_path):
     assert out.returncode == 0, out.stderr
     assert "Built index with 1000000 base pairs" in out.stdout
     assert "Searched 10000000 12bp sequences" in out.stdout
+
+
+def test_single_queries_on_the_host_and_on_the_device_agree(capi, oracle, monkeypatch):
+    """rank / lf / unc_sa / loc_search / reverse_search / locate / mms answer one
+    query from the host arrays of the fm_index; BWT_MI355X_SCALAR=device sends the
+    same call to the GPU as a batch of one.  Both must be the oracle's answer."""
+    capi.mms.argtypes = [C.POINTER(FM), u8p, C.c_int, i32p, i32p]
+    n = 200003
+    text = oracle.gen_genome(n, GENOME_SEED + 5)
+    fo = oracle.make_fmi(text, n)
+    fmi = capi.make_fmi(_p(text), n)
+    from bwt_amd import synth
+    bases = synth.unpack(text, n)
+    rng = np.random.default_rng(8)
+    rows = [0, 1, fo.endloc, n] + [int(x) for x in rng.integers(0, n + 1, 60)]
+    pats = []
+    for t in range(60):
+        m = int(rng.integers(1, 70))
+        j = int(rng.integers(0, n - m + 1))
+        p = bases[j:j + m].copy()
+        if t % 3 == 0:
+            p[int(rng.integers(0, m))] ^= 2
+        if t % 4 == 0 and m > 4:
+            p[int(rng.integers(0, m - 1))] = 5
+        pats.append(p)
+    answers = {}
+    for where in ("host", "device"):
+        if where == "device":
+            monkeypatch.setenv("BWT_MI355X_SCALAR", "device")
+        else:
+            monkeypatch.delenv("BWT_MI355X_SCALAR", raising=False)
+        got = []
+        for r in rows:
+            got.append((capi.lf(fmi, r), capi.unc_sa(fmi, r), tuple(capi.rank(fmi, bytes([c]), r) for c in range(4))))
+        sp, ep = C.c_int(), C.c_int()
+        for p in pats:
+            plain = p.copy()
+            plain[plain == 5] = 0
+            capi.loc_search(fmi, _p(plain), len(p), C.byref(sp), C.byref(ep))
+            got.append((sp.value, ep.value, capi.reverse_search(fmi, _p(plain), len(p)),
+                        capi.locate(fmi, _p(plain), len(p))))
+            got.append((capi.mms(fmi, _p(p), len(p), C.byref(sp), C.byref(ep)), sp.value, ep.value))
+        answers[where] = got
+    assert answers["host"] == answers["device"]
+    k = 0
+    for r in rows:
+        assert answers["host"][k] == (oracle.lf(fo, r), oracle.unc_sa(fo, r), tuple(oracle.rank(fo, c, r) for c in range(4)))
+        k += 1
+    for p in pats:
+        plain = p.copy()
+        plain[plain == 5] = 0
+        s, e = (int(x) for x in oracle.loc_search(fo, plain))
+        assert answers["host"][k][:3] == (s, e, oracle.reverse_search(fo, plain))
+        assert answers["host"][k][3] == oracle.locate(fo, plain)
+        assert answers["host"][k + 1] == tuple(oracle.mms(fo, p))
+        k += 2
+    capi.destroy_fmi(fmi)
+
+
+def test_histhelper_sorts_a_run_of_suffixes(capi, oracle):
+    """histhelper (histsortcomp.h:4): a run of suffix starts that share their first
+    bases, handed over in any order, comes back in suffix-array order, in arr and
+    in aux."""
+    capi.histhelper.restype = None
+    capi.histhelper.argtypes = [u8p, C.c_int, i32p, i32p, C.c_int, C.c_int, C.c_int]
+    n = 60000
+    text = oracle.gen_genome(n, GENOME_SEED + 2)
+    sa = oracle.histsort(text, n).astype(np.int32)
+    rng = np.random.default_rng(2)
+    # the whole array, depth 0, as histsort calls it (histsortcomp.c:171)
+    arr = sa.copy()
+    rng.shuffle(arr)
+    aux = np.zeros_like(arr)
+    capi.histhelper(_p(text), n, _p(arr, i32p), _p(aux, i32p), 0, n + 1, 0)
+    np.testing.assert_array_equal(arr, sa)
+    np.testing.assert_array_equal(aux, sa)
+    # one first-base bucket at depth 1, as the reference's threads call it (histsortcomp.c:107); the rest untouched
+    from bwt_amd import synth
+    bases = synth.unpack(text, n)
+    lo = 1 + int((bases == 0).sum())
+    hi = lo + int((bases == 1).sum())
+    arr = sa.copy()
+    part = arr[lo:hi].copy()
+    rng.shuffle(part)
+    arr[lo:hi] = part
+    before = arr.copy()
+    aux = np.full_like(arr, -5)
+    capi.histhelper(_p(text), n, _p(arr, i32p), _p(aux, i32p), lo, hi, 1)
+    np.testing.assert_array_equal(arr, sa)
+    np.testing.assert_array_equal(aux[lo:hi], sa[lo:hi])
+    assert (aux[:lo] == -5).all() and (aux[hi:] == -5).all() and (before[:lo] == arr[:lo]).all()
+    # runs of zero and one element
+    capi.histhelper(_p(text), n, _p(arr, i32p), _p(aux, i32p), 7, 7, 3)
+    capi.histhelper(_p(text), n, _p(arr, i32p), _p(aux, i32p), 7, 8, 3)
+    np.testing.assert_array_equal(arr, sa)
