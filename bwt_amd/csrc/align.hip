@@ -188,6 +188,8 @@ extern "C" int bwtgpu_align_reads(const bwtgpu_index *ix, const uint8_t *d_text,
   const uint32_t lds_bytes = L.total + (uint32_t)align_up(max_len + 1, 4);
   if (lds_bytes > 64u * 1024u)
     return set_error(kErrArg, "reads of %u bases need %u bytes of LDS (64 KiB at most)", max_len, lds_bytes);
+  if (!ix->d_sa && !ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate anchors");
   BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];

@@ -54,6 +54,7 @@ struct Mailbox {
 Mailbox &thread_mailbox();
 void pool_free(void *p);
 void pool_release_idle();
+void pool_adopt_idle(void *p, size_t bytes, int device);
 template <class T>
 inline hipError_t pool_alloc(T **out, size_t bytes) {
   return pool_alloc(reinterpret_cast<void **>(out), bytes);
@@ -143,6 +144,12 @@ constexpr uint32_t kSymBases = 96;
 constexpr uint32_t kDevSampleShift = 3;
 constexpr uint32_t kDevSampleMask = (1u << kDevSampleShift) - 1u;
 constexpr uint32_t kFileSampleShift = 5;
+// A walk of LF steps from any row of a sound index visits every row once before
+// it returns, so it meets a stored row (row 0 at the latest) within n + 1 steps
+// -- 31 on average on ordinary texts, many more on some repeats, where rows a
+// multiple of the period apart share their residue.  An index assembled from
+// inconsistent parts (a damaged file) may hold a cycle that never does: walks
+// give up after n + 1 steps and report no position.
 
 // The inverse suffix array lives in 64-byte records of twelve positions: the
 // twelve rows, then the 64 bases of text that start at the record's first
@@ -179,6 +186,7 @@ struct bwtgpu_index {
   uint64_t nsym = 0;     // blocks per symbol in d_sym: n/96 + 1
   bwtgpu::SymBlock *d_sym = nullptr;  // [4][nsym]
   uint32_t *d_idxs = nullptr;  // 1 + n/8 sampled SA rows: SA[8 i]
+  bool has_samples = true;     // false: loaded without sampled rows, locate is refused
   // Optional, kept when the index was built from the text and HBM allows
   // (9.6 more bytes per base): the whole suffix array, its inverse, and the
   // text as 16-base little-endian words behind one guard word.  With them a

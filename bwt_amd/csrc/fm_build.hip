@@ -5,6 +5,8 @@
 // the suffix array itself, its inverse, the text in words, the k-mer table.
 // Only what write_index stores ever goes to the host.
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "common.hpp"
 #include "fm_device.hpp"
@@ -339,11 +341,37 @@ __global__ void k_emit_bwt_bytes(const uint8_t *__restrict__ text, const uint32_
 // The suffix array and the build workspace are transient and large (about
 // 21 bytes per base); allocating and freeing them costs more than a millisecond
 // per build, so the calling thread keeps the largest pair it has used on its
-// device until bwtgpu_release_cache().
+// device.  Every thread's cache is on a list: bwtgpu_release_cache() frees them
+// all (a cache whose thread is inside a build at that moment is skipped), and a
+// thread that ends hands its buffers to the idle pool, from where the next
+// request of that size -- or the pool's byte cap -- takes them.
+struct BuildCache;
+static std::mutex g_caches_mu;
+static std::vector<BuildCache *> g_caches;
+
 struct BuildCache {
   int device = -1;
   void *sa = nullptr, *ws = nullptr, *small = nullptr;
   size_t sa_bytes = 0, ws_bytes = 0;
+  std::mutex busy;  // held by the owning thread for the length of a build
+  BuildCache() {
+    std::lock_guard<std::mutex> lock(g_caches_mu);
+    g_caches.push_back(this);
+  }
+  ~BuildCache() {
+    {
+      std::lock_guard<std::mutex> lock(g_caches_mu);
+      for (size_t i = 0; i < g_caches.size(); ++i)
+        if (g_caches[i] == this) {
+          g_caches.erase(g_caches.begin() + (long)i);
+          break;
+        }
+    }
+    // no HIP call here: the main thread gets here after the runtime may have shut down
+    pool_adopt_idle(sa, sa_bytes, device);
+    pool_adopt_idle(ws, ws_bytes, device);
+    pool_adopt_idle(small, 4096, device);
+  }
   void release() {
     if (sa) (void)hipFree(sa);
     if (ws) (void)hipFree(ws);
@@ -446,6 +474,7 @@ int index_build_records(bwtgpu_index *ix, hipStream_t s) {
   void *scratch = nullptr, *own = nullptr;
   int dev = -1;
   (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> building(g_cache.busy);
   if (g_cache.device == dev && g_cache.ws && g_cache.ws_bytes >= bwtgpu_sa_workspace_bytes(n))
     scratch = sa_workspace_free_region(n, g_cache.ws);
   if (!scratch && (uint64_t)n + 1 > (1ull << 22)) {
@@ -465,6 +494,7 @@ int index_build_records(bwtgpu_index *ix, hipStream_t s) {
 
 static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t s,
                                   bwtgpu_index **out) {
+  std::lock_guard<std::mutex> building(g_cache.busy);
   bwtgpu_index *ix = nullptr;
   BWT_TRY(index_alloc(&ix, n));
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
@@ -520,7 +550,14 @@ using namespace bwtgpu;
 extern "C" {
 
 int bwtgpu_release_cache(void) {
-  g_cache.release();
+  {
+    std::lock_guard<std::mutex> lock(g_caches_mu);
+    for (BuildCache *c : g_caches) {
+      if (!c->busy.try_lock()) continue;  // its thread is building: it keeps what it is using
+      c->release();
+      c->busy.unlock();
+    }
+  }
   pool_release_idle();
   return kOk;
 }
@@ -589,6 +626,7 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     set_error(kErrArg, "bad argument");
     return nullptr;
   }
+  std::lock_guard<std::mutex> building(g_cache.busy);
   bwtgpu_index *ix = nullptr;
   if (index_alloc(&ix, n) != kOk) return nullptr;
   alloc_kept_arrays(ix, n);
@@ -630,6 +668,7 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
     return set_error(kErrHip, "no room for the suffix array of %u bases: %s", n, hipGetErrorString(ea));
   }
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
+  std::lock_guard<std::mutex> building(g_cache.busy);
   int rc = cache_reserve(256, ws_bytes);
   if (rc == kOk) rc = sa_build_impl(d_text, n, ix->d_sa, g_cache.ws, ws_bytes, s, nullptr);
   if (rc == kOk) {

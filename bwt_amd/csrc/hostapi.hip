@@ -217,6 +217,8 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
                        uint64_t R, uint32_t *h_sp, uint32_t *h_ep, uint32_t *h_locrow, uint32_t *h_pos) {
   if (!ix || !h_pats || m == 0) return set_error(kErrArg, "bad argument");
   if (R == 0) return kOk;
+  if (h_pos && !ix->d_sa && !ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
   BWT_HIP(hipSetDevice(ix->device));
   {
     // a few reads (the reference's scalar calls are batches of one): through the mailbox, no copies

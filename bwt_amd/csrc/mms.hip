@@ -8,20 +8,30 @@
 
 namespace bwtgpu {
 
-// Bytes [lo, hi) of a global buffer into LDS with 16-byte loads where the
-// alignment allows; returns where byte lo landed.  All threads of the
-// workgroup call it; ends with a barrier.
+// The staged bytes are read through generic pointers (a pattern may lie in LDS
+// or in HBM), i.e. by flat loads, and a read that walks a buffer backwards is
+// compiled to `flat_load base offset:k` with base = address - k.  The hardware
+// decides from `base`, not from base + offset, which aperture a flat access
+// belongs to: a base one byte below the start of the LDS aperture is a memory
+// aperture violation even though the byte loaded lies inside it.  So nothing is
+// ever staged at the very start of LDS: the first kStageHead bytes stay unused.
+constexpr uint32_t kStageHead = 64;
+
+// Bytes [lo, hi) of a global buffer into LDS (behind kStageHead unused bytes)
+// with 16-byte loads where the alignment allows; returns where byte lo landed.
+// All threads of the workgroup call it; ends with a barrier.
 __device__ __forceinline__ const uint8_t *stage_bytes(const uint8_t *__restrict__ g, uint64_t lo, uint64_t hi,
                                                       uint8_t *lds) {
   const uint8_t *src = g + lo;
   const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
   const uint8_t *asrc = src - mis;  // same 16-byte granule as src: inside the allocation
   const uint32_t total = mis + (uint32_t)(hi - lo), vecs = total / 16;
+  uint8_t *dst = lds + kStageHead;
   for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x)
-    reinterpret_cast<uint4 *>(lds)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
-  for (uint32_t i = vecs * 16 + threadIdx.x; i < total; i += blockDim.x) lds[i] = asrc[i];
+    reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(asrc)[i];
+  for (uint32_t i = vecs * 16 + threadIdx.x; i < total; i += blockDim.x) dst[i] = asrc[i];
   __syncthreads();
-  return lds + mis;
+  return dst + mis;
 }
 
 // lds_bytes != 0: the workgroup's patterns are staged in LDS first (coalesced
@@ -53,8 +63,7 @@ k_mms_batch(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint32_t m, u
 // out[4r..4r+3] = forward anchors, backward anchors, last forward position,
 // last backward position (positions 0xFFFFFFFF when there was no anchor).
 __global__ void __launch_bounds__(256)
-k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
-               const uint8_t *__restrict__ reversed, const uint64_t *__restrict__ offsets,
+k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                uint64_t R, int anchor, uint32_t *__restrict__ out, uint32_t lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
@@ -62,17 +71,17 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads,
   const uint64_t rl = r < R ? r : R - 1;  // lanes past the end stage nothing of their own
   const uint64_t o = offsets[rl];
   const int full = (int)(offsets[rl + 1] - o);
-  const uint8_t *fwd = reads + o, *bwd = reversed + o;
-  int bstep = 1;
+  // the reversed read (search_reads.c:112-114 reverses, it does not complement) is
+  // the read's own bytes taken from the other end: no second copy is ever read
+  const uint8_t *fwd = reads + o;
   if (lds_bytes) {
-    // the workgroup's reads lie back to back: one staged copy serves both
-    // directions, the reversed read being the same bytes from the other end
+    // the workgroup's reads lie back to back: one staged copy serves both directions
     const uint64_t lo = offsets[r0], hi = offsets[R < r0 + blockDim.x ? R : r0 + blockDim.x];
     const uint8_t *base = stage_bytes(reads, lo, hi, lds);
     fwd = base + (uint32_t)(o - lo);
-    bwd = fwd + (full - 1);
-    bstep = -1;
   }
+  const uint8_t *bwd = fwd + (full - 1);
+  const int bstep = -1;
   if (r >= R) return;
   uint32_t res[4] = {0, 0, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (int dir = 0; dir < 2; ++dir) {
@@ -155,7 +164,8 @@ int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64
     }
   }
   if (!lds_bytes) nt = 256;
-  BWT_LAUNCH("fm_mms", k_mms_batch, dim3((unsigned)div_up(R, nt)), dim3(nt), lds_bytes, (hipStream_t)stream,
+  BWT_LAUNCH("fm_mms", k_mms_batch, dim3((unsigned)div_up(R, nt)), dim3(nt), lds_bytes ? lds_bytes + kStageHead : 0,
+             (hipStream_t)stream,
              view_of(ix), C, d_pats, m, stride, R, d_matched, d_sp, d_ep, lds_bytes);
   BWT_CHECK_LAUNCH();
   return kOk;
@@ -164,9 +174,12 @@ int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64
 int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads, const uint8_t *d_reversed,
                         const uint64_t *d_offsets, uint64_t R, int anchor, uint32_t *d_out,
                         void *stream) {
-  if (!ix || !d_reads || !d_reversed || !d_offsets || !d_out) return set_error(kErrArg, "null argument");
+  (void)d_reversed;  // never read: see k_search_reads
+  if (!ix || !d_reads || !d_offsets || !d_out) return set_error(kErrArg, "null argument");
   if (anchor < 1) return set_error(kErrArg, "anchor length must be positive");
   if (R == 0) return kOk;
+  if (!ix->d_sa && !ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate anchors");
   BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   CTab C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
@@ -186,8 +199,9 @@ int bwtgpu_search_reads(const bwtgpu_index *ix, const uint8_t *d_reads, const ui
   if (e != hipSuccess) return set_error(kErrHip, "search_reads: %s", hipGetErrorString(e));
   const uint64_t need = align_up(h_span + 32, 16);
   const uint32_t lds_bytes = need <= kMmsLdsBytes ? (uint32_t)need : 0u;
-  BWT_LAUNCH("fm_search_reads", k_search_reads, dim3((unsigned)div_up(R, 256)), dim3(256), lds_bytes, s,
-             view_of(ix), C, d_reads, d_reversed, d_offsets, R, anchor, d_out, lds_bytes);
+  BWT_LAUNCH("fm_search_reads", k_search_reads, dim3((unsigned)div_up(R, 256)), dim3(256),
+             lds_bytes ? lds_bytes + kStageHead : 0, s,
+             view_of(ix), C, d_reads, d_offsets, R, anchor, d_out, lds_bytes);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
@@ -241,29 +255,19 @@ int bwtgpu_search_reads_host(const bwtgpu_index *ix, const uint8_t *h_reads, con
   if (R == 0) return kOk;
   BWT_HIP(hipSetDevice(ix->device));
   const uint64_t total = h_offsets[R];
-  uint8_t *rev = (uint8_t *)malloc(total ? total : 1);
-  if (!rev) return set_error(kErrArg, "out of host memory");
-  for (uint64_t r = 0; r < R; ++r) {  // search_reads.c:112-114: plain reversal
-    const uint64_t a = h_offsets[r], b = h_offsets[r + 1];
-    for (uint64_t k = 0; k < b - a; ++k) rev[a + k] = h_reads[b - 1 - k];
-  }
-  void *d_reads = nullptr, *d_rev = nullptr, *d_off = nullptr, *d_out = nullptr;
+  void *d_reads = nullptr, *d_off = nullptr, *d_out = nullptr;
   hipError_t e = hipMalloc(&d_reads, total + 16);
-  if (e == hipSuccess) e = hipMalloc(&d_rev, total + 16);
   if (e == hipSuccess) e = hipMalloc(&d_off, (R + 1) * 8);
   if (e == hipSuccess) e = hipMalloc(&d_out, R * 16);
   int rc = kOk;
   if (e == hipSuccess) e = hipMemcpy(d_reads, h_reads, total, hipMemcpyHostToDevice);
-  if (e == hipSuccess) e = hipMemcpy(d_rev, rev, total, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_off, h_offsets, (R + 1) * 8, hipMemcpyHostToDevice);
   if (e == hipSuccess)
-    rc = bwtgpu_search_reads(ix, (const uint8_t *)d_reads, (const uint8_t *)d_rev, (const uint64_t *)d_off,
+    rc = bwtgpu_search_reads(ix, (const uint8_t *)d_reads, nullptr, (const uint64_t *)d_off,
                              R, anchor, (uint32_t *)d_out, nullptr);
   if (e == hipSuccess && rc == kOk) e = hipMemcpy(h_out, d_out, R * 16, hipMemcpyDeviceToHost);
   if (e != hipSuccess) rc = set_error(kErrHip, "search_reads buffers: %s", hipGetErrorString(e));
-  free(rev);
   if (d_reads) (void)hipFree(d_reads);
-  if (d_rev) (void)hipFree(d_rev);
   if (d_off) (void)hipFree(d_off);
   if (d_out) (void)hipFree(d_out);
   return rc;

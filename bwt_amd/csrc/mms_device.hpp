@@ -188,7 +188,7 @@ __device__ __forceinline__ uint32_t unc_sa_dev(const IndexView &v, uint32_t idx)
   uint32_t steps = 0;
   while (idx & kDevSampleMask) {
     idx = lf_step(v, idx);
-    ++steps;
+    if (++steps > v.n || idx > v.n) return 0xFFFFFFFFu;  // not the LF map of a text
   }
   uint64_t x = (uint64_t)v.idxs[idx >> kDevSampleShift] + steps;
   if (x > v.n) x -= (uint64_t)v.n + 1;

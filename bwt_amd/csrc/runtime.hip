@@ -32,6 +32,32 @@ std::mutex g_pool_mu;
 std::unordered_map<void *, Pooled> g_live;  // handed out by pool_alloc
 std::vector<Pooled> g_idle;
 constexpr size_t kPoolMaxIdle = 48;
+// Idle buffers may hold at most a quarter of the device's memory: an index of
+// the largest text (39 GB at 3.1 Gbp) still finds its buffers again, and what a
+// process no longer uses does not stay out of reach of everything else in it.
+size_t g_idle_bytes = 0, g_idle_cap = 0;
+
+size_t idle_cap_locked() {
+  if (!g_idle_cap) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || !total_b) {
+      (void)hipGetLastError();
+      total_b = (size_t)64 << 30;
+    }
+    g_idle_cap = total_b / 4;
+  }
+  return g_idle_cap;
+}
+
+// with the pool lock held: takes the longest-idle buffers off the list until count and bytes fit
+void trim_locked(std::vector<void *> &drop) {
+  const size_t cap = idle_cap_locked();
+  while (!g_idle.empty() && (g_idle.size() > kPoolMaxIdle || g_idle_bytes > cap)) {
+    drop.push_back(g_idle.front().p);
+    g_idle_bytes -= g_idle.front().bytes;
+    g_idle.erase(g_idle.begin());
+  }
+}
 }  // namespace
 
 hipError_t pool_alloc(void **out, size_t bytes) {
@@ -46,6 +72,7 @@ hipError_t pool_alloc(void **out, size_t bytes) {
       if (g_idle[i].bytes == bytes && g_idle[i].device == dev) {
         const Pooled hit = g_idle[i];
         g_idle.erase(g_idle.begin() + (long)i);
+        g_idle_bytes -= hit.bytes;
         g_live[hit.p] = hit;
         *out = hit.p;
         return hipSuccess;
@@ -69,21 +96,30 @@ hipError_t pool_alloc(void **out, size_t bytes) {
 // The caller has made sure that no work in flight still uses the buffer.
 void pool_free(void *p) {
   if (!p) return;
-  void *drop = p;  // what goes back to the driver: p itself unless the pool keeps it
+  std::vector<void *> drop;  // what goes back to the driver
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     auto it = g_live.find(p);
     if (it != g_live.end()) {
       g_idle.push_back(it->second);
+      g_idle_bytes += it->second.bytes;
       g_live.erase(it);
-      drop = nullptr;
-      if (g_idle.size() > kPoolMaxIdle) {  // the longest-idle buffer makes room
-        drop = g_idle.front().p;
-        g_idle.erase(g_idle.begin());
-      }
+      trim_locked(drop);  // the longest-idle buffers make room
+    } else {
+      drop.push_back(p);
     }
   }
-  if (drop) (void)hipFree(drop);
+  for (void *d : drop) (void)hipFree(d);
+}
+
+// A buffer that was hipMalloc'd outside the pool joins the idle list (a thread
+// that ends hands over its build workspace this way).  Makes no HIP call: it may
+// run while the process is shutting down.
+void pool_adopt_idle(void *p, size_t bytes, int device) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  g_idle.push_back(Pooled{p, bytes, device});
+  g_idle_bytes += bytes;
 }
 
 void pool_release_idle() {
@@ -91,6 +127,7 @@ void pool_release_idle() {
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     drop.swap(g_idle);
+    g_idle_bytes = 0;
   }
   for (const Pooled &d : drop) (void)hipFree(d.p);
 }

@@ -286,7 +286,10 @@ k_locate_few(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_
   }
   while (idx & kDevSampleMask) {
     idx = lf_step(v, idx);
-    ++steps;
+    if (++steps > v.n || idx > v.n) {  // not the LF map of a text
+      pos[r] = 0xFFFFFFFFu;
+      return;
+    }
   }
   uint64_t x = (uint64_t)v.idxs[idx >> kDevSampleShift] + steps;
   if (x > v.n) x -= (uint64_t)v.n + 1;
@@ -388,7 +391,10 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
         active[s] = false;
       } else if (step[s]) {
         idx[s] = nxt[s];
-        ++steps[s];
+        if (++steps[s] > v.n || nxt[s] > v.n) {  // not the LF map of a text
+          pos[mine[s]] = 0xFFFFFFFFu;
+          active[s] = false;
+        }
       }
     }
   }
@@ -576,6 +582,8 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
                      bwtgpu_locate_workspace_bytes());
   if ((uintptr_t)d_ws & 7u) return set_error(kErrArg, "workspace must be 8-byte aligned");
   if (R == 0) return kOk;
+  if (!ix->d_sa && !ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
   if (ix->d_sa) {
     BWT_LAUNCH("fm_locate", k_locate_sa, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows,
                R, d_pos);

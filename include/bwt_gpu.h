@@ -262,8 +262,10 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
 int bwtgpu_mms(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                uint64_t R, int32_t *d_matched, uint32_t *d_sp, uint32_t *d_ep, void *stream);
 /* Replaces the per-read body of search_reads (search_reads.c:115-153): read r
- * is the encoded bytes d_reads[d_offsets[r] .. d_offsets[r+1]) (0..3, 5 = N),
- * d_reversed holds each read reversed in the same slots (search_reads.c:112-114).
+ * is the encoded bytes d_reads[d_offsets[r] .. d_offsets[r+1]) (0..3, 5 = N).
+ * The reversed read of search_reads.c:112-114 is a plain reversal, so the kernel
+ * reads the same bytes from the other end: d_reversed is never read and may be
+ * NULL (the parameter remains for callers that already pass a reversed copy).
  * d_out[4r..4r+3] = forward anchors, backward anchors, position of the last
  * forward anchor, of the last backward anchor (0xFFFFFFFF: none); an anchor is
  * a maximum mappable suffix of at least `anchor` bases (20 in the reference). */
