@@ -61,6 +61,9 @@ SIGNATURES = {
     "bwtgpu_lf_host": (C.c_int, [vp, vp, u64, vp]),
     "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
     "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_search_packed": (C.c_int, [vp, vp, u32, u64, vp, vp, vp, vp]),
+    "bwtgpu_pack_reads_host": (C.c_int, [vp, u32, u64, u64, vp]),
+    "bwtgpu_search_packed_host": (C.c_int, [vp, vp, u32, u64, vp, vp, vp, vp]),
     "bwtgpu_search_static": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bwtgpu_sa_bucket_counts": (C.c_int, [vp, u32, vp, vp]),
     "bwtgpu_sa_build_range": (C.c_int, [vp, u32, u32, u32, vp, vp, u64, vp, vp, vp, vp, sz, vp]),

@@ -226,6 +226,12 @@ inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 // address of the static scratch array bwtgpu_search_static uses.
 int static_scratch_setup(int device, void **out = nullptr);
 
+// hoststream.hip: host batches through pinned staging, packed on the way
+bool host_batch_prefers_packing(uint32_t m, uint64_t stride, uint64_t R);
+int search_host_streamed(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride, uint64_t R,
+                         uint32_t *h_sp, uint32_t *h_ep, uint32_t *h_locrow, uint32_t *h_pos);
+void pinned_release_idle();
+
 // index.hip
 int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known

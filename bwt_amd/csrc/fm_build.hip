@@ -559,6 +559,7 @@ int bwtgpu_release_cache(void) {
     }
   }
   pool_release_idle();
+  pinned_release_idle();
   return kOk;
 }
 

@@ -254,6 +254,10 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
       return kOk;
     }
   }
+  // large batches of reads that do not overlap: packed by host threads, chunk by chunk, while the
+  // chunks before are on the wire and in the kernels
+  if (host_batch_prefers_packing(m, stride, R))
+    return search_host_streamed(ix, h_pats, m, stride, R, h_sp, h_ep, h_locrow, h_pos);
   const uint64_t chunk_max = stride ? (1ull << 30) / (stride > m ? stride : m) + 1 : R;
   const uint64_t chunk = R < chunk_max ? R : chunk_max;
   Dev pats, sp, ep, lr, pos, ws, lws;

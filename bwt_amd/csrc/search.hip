@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
          uint64_t stride, uint64_t R, uint32_t m, uint32_t *__restrict__ d_sp,
          uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
-         unsigned long long *__restrict__ counters) {
+         unsigned long long *__restrict__ counters, uint64_t wstride, uint64_t rstride) {
+  // !FUSED: word w of read r is packed[w * wstride + r * rstride] -- (R, 1) for the
+  // word-major form k_pack_reads writes, (1, words per read) for reads packed
+  // one after the other (bwtgpu_search_packed)
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const uint32_t t = threadIdx.x;
   const uint64_t r0 = (uint64_t)blockIdx.x * blockDim.x;
@@ -131,7 +134,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     }
     lw = wbase + t;  // only this lane reads its own words: no barrier needed
   }
-  auto word_at = [&](uint32_t w) -> uint32_t { return FUSED ? lw[w * nt] : packed[(uint64_t)w * R + r]; };
+  auto word_at = [&](uint32_t w) -> uint32_t { return FUSED ? lw[w * nt] : packed[(uint64_t)w * wstride + r * rstride]; };
   uint32_t n_blk = 0, n_txt = 0, n_ent = 0, n_pat = 1, n_kmr = 0;
   if (r < R) {
   int i = -2;
@@ -489,10 +492,10 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
     if (ix->d_isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
     else
       BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
     BWT_CHECK_LAUNCH();
     return kOk;
   }
@@ -503,16 +506,16 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   if (d_counters) {
     if (ix->d_isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
   } else if (ix->d_isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
-               d_sp, d_ep, d_locrow, d_counters);
+               d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
   } else {
     BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R,
-               m, d_sp, d_ep, d_locrow, d_counters);
+               m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
   }
   BWT_CHECK_LAUNCH();
   return kOk;
@@ -524,6 +527,30 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
   if (ix) BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
   return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_ws, ws_bytes, nullptr,
                      (hipStream_t)stream);
+}
+
+int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,
+                         uint32_t *d_ep, uint32_t *d_locrow, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !d_words || !d_sp || !d_ep) return set_error(kErrArg, "null argument");
+  if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
+  if (R == 0) return kOk;
+  if (div_up(R, 256) > 0x7FFFFFFFull) return set_error(kErrArg, "too many reads for one launch");
+  BWT_TRY(index_ready_for_search(ix, s));
+  CTable C;
+  for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
+  const IndexView v = view_of(ix);
+  const dim3 grid((unsigned)div_up(R, 256)), block(256);
+  const uint64_t words = (m + 15) / 16;
+  if (ix->d_isa)
+    BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, d_words, (const uint8_t *)nullptr,
+               (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr, (uint64_t)1, words);
+  else
+    BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, d_words,
+               (const uint8_t *)nullptr, (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr,
+               (uint64_t)1, words);
+  BWT_CHECK_LAUNCH();
+  return kOk;
 }
 
 int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,

@@ -650,6 +650,24 @@ int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride
   return 0; /* 0xFFFFFFFF reads as -1 */
 }
 
+void fmi_pack_reads(const char *pats, int len, long stride, long nreads, unsigned *words) {
+  /* host threads only: no device is needed to pack */
+  if (bwtgpu_pack_reads_host((const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads, words))
+    report("pack reads");
+}
+
+int fmi_search_batch_packed(const fm_index *fmi, const unsigned *words, int len, long nreads,
+                            int *sp, int *ep, int *pos) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  if (bwtgpu_search_packed_host(ix, words, (uint32_t)len, (uint64_t)nreads, (uint32_t *)sp, (uint32_t *)ep, NULL,
+                                (uint32_t *)pos)) {
+    report("packed search");
+    return -1;
+  }
+  return 0;
+}
+
 int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos) {
   bwtgpu_index *ix = device_index(fmi);
   if (!ix) return -1;

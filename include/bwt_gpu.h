@@ -216,6 +216,13 @@ size_t bwtgpu_search_workspace_bytes(uint64_t R, uint32_t m);
 int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
                   uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
                   uint32_t *d_locrow, void *d_ws, size_t ws_bytes, void *stream);
+/* The same search for reads that are already packed: read r is the (m+15)/16
+ * 32-bit words at d_words + r * ((m+15)/16), base k of the read at bits
+ * 2 (k % 16) of word k / 16, zero bits above the last base (the format
+ * bwtgpu_pack_reads_host writes).  No workspace.  No counterpart in the
+ * reference, which keeps reads one base per byte. */
+int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R,
+                         uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *stream);
 /* bwtgpu_search for callers that cannot allocate or hold a workspace (code
  * under HIP graph capture, tight serving loops): no counterpart in the
  * reference.  Same inputs, outputs and results as bwtgpu_search; the packed-read
@@ -336,6 +343,21 @@ int bwtgpu_bwt_from_sa_host(const uint8_t *h_text, const uint32_t *h_sa, uint32_
 int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m,
                        uint64_t stride, uint64_t R, uint32_t *h_sp, uint32_t *h_ep,
                        uint32_t *h_locrow, uint32_t *h_pos);
+/* Large batches (32768 reads or more that do not overlap) stream: host threads
+ * (BWT_MI355X_HOST_THREADS, default 8) pack a chunk to 2 bits per base into pinned
+ * memory while the chunk before is being copied and searched and the results of
+ * the one before that are copied out, so a quarter of the bytes cross PCIe and
+ * nothing waits for the whole batch.
+ * bwtgpu_pack_reads_host: that packing alone, for callers that keep their reads
+ * packed: R reads of m bases at h_pats + r * stride -> (m+15)/16 words per read
+ * (format: see bwtgpu_search_packed).
+ * bwtgpu_search_packed_host: bwtgpu_search_host for reads in that format; from
+ * pinned memory nothing but DMA and the kernels is left. */
+int bwtgpu_pack_reads_host(const uint8_t *h_pats, uint32_t m, uint64_t stride, uint64_t R,
+                           uint32_t *h_words);
+int bwtgpu_search_packed_host(const bwtgpu_index *ix, const uint32_t *h_words, uint32_t m,
+                              uint64_t R, uint32_t *h_sp, uint32_t *h_ep, uint32_t *h_locrow,
+                              uint32_t *h_pos);
 /* reverse_search (seqindex.c:228-242) per read: 0 if the interval emptied before
  * the last step, else ep - sp + 1 as the reference returns it */
 int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m,

@@ -99,6 +99,15 @@ int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, lon
 /* locate per read: position, or -1 */
 int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride,
                      long nreads, int *pos);
+/* Reads packed to 2 bits per base, for callers that hold many of them: read r
+ * becomes the (len+15)/16 unsigned words at words + r * ((len+15)/16), base k at
+ * bits 2 (k % 16) of word k / 16.  fmi_search_batch_packed = loc_search, and
+ * locate when pos is not NULL (-1 where locate returns -1), per packed read;
+ * sp, ep, pos may each be NULL.  From pinned host memory this is the fastest way
+ * in: a quarter of the bytes, no packing on the way. */
+void fmi_pack_reads(const char *pats, int len, long stride, long nreads, unsigned *words);
+int fmi_search_batch_packed(const fm_index *fmi, const unsigned *words, int len, long nreads,
+                            int *sp, int *ep, int *pos);
 /* unc_sa per row */
 int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos);
 
