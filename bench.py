@@ -305,7 +305,7 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
             if traffic is not None else None,
             "bytes_per_read": bpr, "loads": loads, "counting_pass_matches": counted_ok, "kernel_ms": k_ms,
             "requested_lines_per_read": (loads["rank_blocks_16B"] + loads["text_windows_16B"]
-                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries_8B"]) / R,
+                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries"]) / R,
             "what": "rank 0's slice; bytes counted by the kernel's counting build",
         },
         "locate": {"kernel_ms": l_ms, "value": R / (l_ms * 1e-3) if l_ms else None, "unit": "rows/s",
@@ -647,13 +647,13 @@ def main():
             # distinct lines a read asks for, from the counting build: rank blocks, record lines (the
             # text window and the ISA entry share one), SA entries, table entries
             "requested_lines_per_read": (loads["rank_blocks_16B"] + loads["text_windows_16B"]
-                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries_8B"]) / R,
+                                         + loads["sa_isa_entries_4B"] / 2 + loads["kmer_entries"]) / R,
             "bytes_per_read": bpr,
             "loads": loads,
             "counting_pass_matches": counted_ok,
             "kernel_ms": k_ms,
             "what": "bytes the kernel loads and stores, counted per batch by its counting build "
-                    "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries, 8 B table entry, the read itself, "
+                    "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries, 8 or 12 B table entry, the read itself, "
                     "12 B out)",
             "reads_packed_in_kernel": fused,
         },

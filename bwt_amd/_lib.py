@@ -42,6 +42,7 @@ SIGNATURES = {
     "bwtgpu_index_rank_rows16": (C.c_int, [vp, vp]),
     "bwtgpu_index_rank_rows": (C.c_int, [vp, u32, vp]),
     "bwtgpu_index_device_bytes": (sz, [vp]),
+    "bwtgpu_index_kmer_table": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
     "bwtgpu_mms": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bwtgpu_search_reads": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, vp, vp]),
     "bwtgpu_align_reads": (C.c_int, [vp, vp, vp, vp, u64, C.c_int, u32, vp, vp, vp, vp]),

@@ -203,6 +203,11 @@ struct bwtgpu_index {
   // bases starts there.
   uint32_t *d_kmer = nullptr;
   uint32_t kmer_k = 0;
+  // Words per table entry: 1 = the interval start alone; 2 = the start and, next to it,
+  // SA[start] -- the text position of the string when it occurs exactly once (half of
+  // all strings of ceil(log4 n) bases that occur at all), which saves such a search the
+  // suffix-array line.  Two words when the index keeps its suffix array.
+  uint32_t kmer_w = 1;
   int device = 0;
   // What make_fmi (seqindex.c:161-189) produces is complete when a build or a
   // load returns.  The arrays that only speed searches up (position records,

@@ -15,6 +15,7 @@ struct IndexView {
   const uint32_t *text2;
   const uint32_t *kmer;   // null unless the index has the k-mer interval table
   uint32_t kmer_k;
+  uint32_t kmer_w;        // words per table entry: 1 (start) or 2 (start, SA[start])
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
@@ -22,7 +23,7 @@ struct IndexView {
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->kmer_k, ix->nsym, ix->n, ix->endloc};
+                   ix->d_kmer,   ix->kmer_k, ix->kmer_w, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
@@ -45,23 +46,41 @@ __device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
 }
 
 // The SA interval [sp, return value) of the string numbered x in the k-mer
-// table; empty when the two are equal.
-__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp) {
-  // one 8-byte load at a 4-byte aligned address: both starts in one request
-  uint64_t both;
-  __builtin_memcpy(&both, v.kmer + x, sizeof both);
-  sp = (uint32_t)both;
-  uint32_t ep = (uint32_t)(both >> 32);
+// table; empty when the two are equal.  pos (when the table has two words per
+// entry, else 0xFFFFFFFF): SA[sp], the text position of the string's first
+// occurrence in row order -- its only one when the interval is a single row.
+__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp, uint32_t &pos) {
+  uint32_t ep;
+  if (v.kmer_w == 2) {
+    // start and position of x, start of x + 1: three words of one 16-byte-or-less span
+    const uint32_t *e = v.kmer + 2ull * x;
+    uint64_t mine;
+    __builtin_memcpy(&mine, e, sizeof mine);
+    sp = (uint32_t)mine;
+    pos = (uint32_t)(mine >> 32);
+    ep = e[2];
+  } else {
+    // one 8-byte load at a 4-byte aligned address: both starts in one request
+    uint64_t both;
+    __builtin_memcpy(&both, v.kmer + x, sizeof both);
+    sp = (uint32_t)both;
+    ep = (uint32_t)(both >> 32);
+    pos = 0xFFFFFFFFu;
+  }
   // rows of suffixes shorter than the table's strings that lie between the two;
   // every pair is read (unused ones name no string): the loads are uniform and
   // issue together
-  const uint2 *gaps = reinterpret_cast<const uint2 *>(v.kmer + (1ull << (2 * v.kmer_k)) + 2);
+  const uint2 *gaps = reinterpret_cast<const uint2 *>(v.kmer + ((uint64_t)v.kmer_w << (2 * v.kmer_k)) + 2);
 #pragma unroll
   for (uint32_t g = 0; g < kKmerMaxGaps; ++g) {
     const uint2 e = gaps[g];
-    ep -= e.x == x + 1 ? e.y : 0u;
+    ep -= (uint64_t)e.x == (uint64_t)x + 1 ? e.y : 0u;  // x + 1 does not fit 32 bits for the last string of 16 bases
   }
   return ep;
+}
+__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp) {
+  uint32_t pos;
+  return kmer_interval(v, x, sp, pos);
 }
 
 // 16 bases of text starting at position o (o >= -15), base k of the result at

@@ -339,13 +339,24 @@ __device__ __forceinline__ void kmer_extend(const IndexView &v, uint2 iv, uint2 
 
 template <bool LAST>
 __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
-                             uint32_t *__restrict__ dst_start, uint32_t j) {
+                             uint32_t *__restrict__ dst_start, uint32_t j, const uint32_t *__restrict__ sa) {
   // one thread per string x of j bases: the two blocks its interval ends fall
   // in serve all four extensions c.x
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t parents = 1ull << (2 * j);
   if (p >= parents) return;
   const uint2 iv = src[p];
+  if (LAST && sa) {
+    // two-word entries: the start and, where the string occurs, SA[start].  Starts grow
+    // with the string number, so neighbouring threads read neighbouring rows of the array.
+    uint2 o[4];
+    kmer_extend(v, iv, o);
+    uint2 *entries = reinterpret_cast<uint2 *>(dst_start);
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c)
+      entries[(uint64_t)c * parents + p] = make_uint2(o[c].x, (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u);
+    return;
+  }
   if (LAST) {
     const uint32_t a = iv.x - (iv.x > v.endloc);
     const IndexBlock *ba = v.blocks + (a >> 6);
@@ -379,11 +390,12 @@ constexpr uint32_t kKmerHeadLevels = 5;  // 4^4 strings is what one workgroup ex
 // off the index by walking LF from the row of the empty suffix
 // (seqindex.c:214-219).  Unused pairs name no string.
 __global__ void __launch_bounds__(256) k_kmer_head(IndexView v, KmerFirst C, uint32_t top, uint32_t K,
-                                                    uint2 *__restrict__ dst, uint32_t *__restrict__ tab) {
+                                                    uint2 *__restrict__ dst, uint32_t *__restrict__ tab,
+                                                    uint32_t entry_words) {
   const uint32_t t = threadIdx.x;
   if (blockIdx.x == 1) {
     if (t) return;
-    uint32_t *trailer = tab + (1ull << (2 * K));
+    uint32_t *trailer = tab + ((uint64_t)entry_words << (2 * K));
     trailer[0] = v.n + 1;
     trailer[1] = 0;
     uint2 *gaps = reinterpret_cast<uint2 *>(trailer + 2);
@@ -421,18 +433,24 @@ __global__ void __launch_bounds__(256) k_kmer_head(IndexView v, KmerFirst C, uin
   }
 }
 
-// Table size: the smallest k with 4^k >= n, so that the interval of a string
-// of k bases is a single row more often than not, at most 4^15 entries
-// (4 GiB); BWT_MI355X_KMER=<k> overrides (0: no table), BWT_MI355X_COMPACT
-// means none.
-static uint32_t kmer_table_k(uint32_t n) {
+// Table size.  An index that keeps its suffix array gets two-word entries, and a
+// string that occurs once then costs a search one line for the table and one for
+// the position record; the share of such strings among those that occur is
+// exp(-n / 4^k), so the table is made sparse: the smallest k with 4^k >= 2 n
+// (46 Mbp: k = 14, 2.1 GB; 3.1 Gbp: k = 16, 34 GB -- the GPU has 288).  An index
+// without its suffix array (one-word entries, every search goes on with rank
+// steps) gets the smallest k with 4^k >= n.  At most 4^16 entries: a string
+// number is 32 bits.  BWT_MI355X_KMER=<k> overrides (0: no table),
+// BWT_MI355X_COMPACT means none; when HBM is short the next smaller k is tried.
+static uint32_t kmer_table_k(uint32_t n, bool two_words) {
   if (getenv("BWT_MI355X_COMPACT")) return 0;
   if (const char *e = getenv("BWT_MI355X_KMER")) {
     const long k = strtol(e, nullptr, 10);
-    return k < 2 ? 0u : (k > 15 ? 15u : (uint32_t)k);
+    return k < 2 ? 0u : (k > 16 ? 16u : (uint32_t)k);
   }
+  const uint64_t want = two_words ? 2ull * n : (uint64_t)n;
   uint32_t k = 0;
-  while (k < 15 && (1ull << (2 * k)) < (uint64_t)n) ++k;
+  while (k < 16 && (1ull << (2 * k)) < want) ++k;
   return k < 6 ? 0u : k;
 }
 
@@ -446,20 +464,26 @@ static uint32_t kmer_table_k(uint32_t n) {
 // most K - 1 such suffixes; the pairs list the strings s.AA..A, and a lookup
 // subtracts the rows of the pairs that name the next string.
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
-  const uint32_t K = kmer_table_k(ix->n);
+  const uint32_t W = ix->d_sa ? 2u : 1u;  // with the suffix array at hand, entries carry SA[start] as well
+  uint32_t K = kmer_table_k(ix->n, W == 2);
   if (K == 0) return kOk;
-  static_assert(kKmerMaxGaps >= 14, "one pair per suffix shorter than the longest table string");
-  const uint64_t entries = 1ull << (2 * K);
-  const size_t tab_bytes = (entries + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2);
+  static_assert(kKmerMaxGaps >= 15, "one pair per suffix shorter than the longest table string");
+  uint64_t entries = 0;
   uint32_t *tab = nullptr;
   uint2 *tmp_a = nullptr, *tmp_b = nullptr;
-  if (pool_alloc(&tab, tab_bytes) != hipSuccess ||
-      pool_alloc(&tmp_a, (entries / 4) * sizeof(uint2)) != hipSuccess ||
-      pool_alloc(&tmp_b, (entries / 16) * sizeof(uint2)) != hipSuccess) {
-    (void)hipGetLastError();  // short of memory: searches start from the first base instead
+  for (;; --K) {
+    entries = 1ull << (2 * K);
+    const size_t tab_bytes = (entries * W + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2);
+    if (pool_alloc(&tab, tab_bytes) == hipSuccess && pool_alloc(&tmp_a, (entries / 4) * sizeof(uint2)) == hipSuccess &&
+        pool_alloc(&tmp_b, (entries / 16) * sizeof(uint2)) == hipSuccess)
+      break;
+    (void)hipGetLastError();  // short of memory: a smaller table, or none (searches then start from the first base)
     pool_free(tab);
     pool_free(tmp_a);
-    return kOk;
+    pool_free(tmp_b);
+    tab = nullptr;
+    tmp_a = tmp_b = nullptr;
+    if (K <= 6 || getenv("BWT_MI355X_KMER")) return kOk;
   }
   // level j < K lives in tmp_a when K - 1 - j is even, in tmp_b otherwise
   auto buf = [&](uint32_t j) { return ((K - 1 - j) & 1u) ? tmp_b : tmp_a; };
@@ -467,16 +491,16 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   KmerFirst first;
   for (uint32_t c = 0; c < 5; ++c) first.c[c] = ix->C[c];
   const uint32_t top = K - 1 < kKmerHeadLevels ? K - 1 : kKmerHeadLevels;
-  BWT_LAUNCH("kmer_head", k_kmer_head, dim3(2), dim3(256), 0, s, v, first, top, K, buf(top), tab);
+  BWT_LAUNCH("kmer_head", k_kmer_head, dim3(2), dim3(256), 0, s, v, first, top, K, buf(top), tab, W);
   hipError_t e = hipGetLastError();
   for (uint32_t j = top; j < K && e == hipSuccess; ++j) {
     const uint64_t parents = 1ull << (2 * j);
     if (j + 1 < K)
       BWT_LAUNCH("kmer_level", k_kmer_level<false>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
-                 buf(j), buf(j + 1), (uint32_t *)nullptr, j);
+                 buf(j), buf(j + 1), (uint32_t *)nullptr, j, (const uint32_t *)nullptr);
     else
       BWT_LAUNCH("kmer_level", k_kmer_level<true>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
-                 buf(j), (uint2 *)nullptr, tab, j);
+                 buf(j), (uint2 *)nullptr, tab, j, W == 2 ? (const uint32_t *)ix->d_sa : (const uint32_t *)nullptr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -489,6 +513,7 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   }
   ix->d_kmer = tab;
   ix->kmer_k = K;
+  ix->kmer_w = W;
   return kOk;
 }
 
@@ -496,7 +521,7 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
 // arrays this index can still get.
 void index_defer_search_arrays(bwtgpu_index *ix) {
   ix->want_records = ix->d_sa && ix->d_text2 && !ix->d_isa;
-  ix->want_kmer = !ix->d_kmer && kmer_table_k(ix->n) != 0;
+  ix->want_kmer = !ix->d_kmer && kmer_table_k(ix->n, ix->d_sa != nullptr) != 0;
   ix->search_ready.store(!(ix->want_records || ix->want_kmer), std::memory_order_release);
 }
 
@@ -665,13 +690,21 @@ int bwtgpu_index_info(const bwtgpu_index *ix, uint32_t *n, uint32_t *endloc, uin
   return kOk;
 }
 
+int bwtgpu_index_kmer_table(const bwtgpu_index *ix, uint32_t *k, uint32_t *entry_words) {
+  if (!ix) return set_error(kErrArg, "null index");
+  if (k) *k = ix->d_kmer ? ix->kmer_k : 0u;
+  if (entry_words) *entry_words = ix->d_kmer ? ix->kmer_w : 0u;
+  return kOk;
+}
+
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   if (!ix) return 0;
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
          (ix->d_sa ? ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
          (ix->d_isa ? pos_record_count(ix->n) * sizeof(PosRecord) : 0) +
-         (ix->d_kmer ? ((1ull << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2) : 0);
+         (ix->d_kmer ? (((uint64_t)ix->kmer_w << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2)
+                     : 0);
 }
 
 int bwtgpu_index_compact(bwtgpu_index *ix) {

@@ -139,6 +139,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   if (r < R) {
   int i = -2;
   uint32_t word = 0, c, sp = 0, ep = 0;
+  uint32_t table_pos = 0xFFFFFFFFu;  // SA[sp] when the k-mer table supplied it (a two-word table, a single row)
   const uint32_t K = v.kmer_k;
   if (K && m >= K) {
     // the last K bases as a base-4 number, first base most significant
@@ -149,14 +150,15 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     uint32_t x = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (2 * (a & 15u)));  // base a in the low bits
     x = __brev(x);
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);  // base a in the top bits
-    uint32_t e_sp;
-    const uint32_t e_ep = kmer_interval(v, x >> (32 - 2 * K), e_sp);
+    uint32_t e_sp, e_pos;
+    const uint32_t e_ep = kmer_interval(v, x >> (32 - 2 * K), e_sp, e_pos);
     if (COUNT) ++n_kmr;
     if (e_ep > e_sp) {
       sp = e_sp;
       ep = e_ep;
       word = w0;
       i = (int)a - 1;
+      if (e_ep - e_sp == 1) table_pos = e_pos;  // the one occurrence of the string: SA[sp] without the lookup
     }
   }
   if (i == -2) {  // no table, a short read, or a string the text does not hold: step by step
@@ -194,8 +196,9 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   }
   if (VERIFY && !early && i >= 0 && ep - sp == 1) {
     const uint32_t rem = (uint32_t)i + 1;  // read bases 0..i are still to be prepended
-    const uint32_t pos = v.sa[sp];
-    if (COUNT) n_ent += 2;  // this and the one ISA entry read below
+    // no rank step has moved sp since the table lookup exactly when the table's interval was the single row
+    const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : v.sa[sp];
+    if (COUNT) n_ent += table_pos != 0xFFFFFFFFu ? 1 : 2;  // the SA entry unless the table had it, and the one ISA entry read below
     const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
     // the highest read base j in [jmin, rem) that differs from text[pos - rem + j];
     // the record of position pos - rem + 48 g holds the text for read words 3g..3g+2

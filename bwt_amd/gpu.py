@@ -162,9 +162,18 @@ class GpuIndex:
         check(lib.bwtgpu_search_profile(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(ws),
                                         ws.numel(), loads, _stream()))
         blk, txt, ent, pat, kmr = (int(x) for x in loads)
+        k, w = self.kmer_table
+        per_entry = 12 if w == 2 else 8  # two neighbouring starts, and the position between them in a two-word table
         return {"rank_blocks_16B": blk, "text_windows_16B": txt, "sa_isa_entries_4B": ent,
-                "pattern_words_4B": pat, "kmer_entries_8B": kmr,
-                "bytes": 16 * blk + 16 * txt + 4 * ent + 4 * pat + 8 * kmr}, sp, ep
+                "pattern_words_4B": pat, "kmer_entries": kmr, "kmer_entry_bytes": per_entry, "kmer_k": k,
+                "bytes": 16 * blk + 16 * txt + 4 * ent + 4 * pat + per_entry * kmr}, sp, ep
+
+    @property
+    def kmer_table(self):
+        """(bases per string, words per entry) of the k-mer table, (0, 0) when there is none (yet)."""
+        k, w = C.c_uint32(), C.c_uint32()
+        check(_lib.load().bwtgpu_index_kmer_table(self.h, C.byref(k), C.byref(w)))
+        return int(k.value), int(w.value)
 
     def attach_text(self, text):
         """Give an index loaded from its stored parts the text it was built from

@@ -152,11 +152,18 @@ int bwtgpu_index_rank_rows16(const bwtgpu_index *ix, uint32_t *h_rows);
  * 1+(n+blocksize-1)/blocksize rows. */
 int bwtgpu_index_rank_rows(const bwtgpu_index *ix, uint32_t blocksize, uint32_t *h_rows);
 size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix);
+/* The k-mer table an index holds at this moment (it is made on first search):
+ * *k = bases per string (0: none), *entry_words = 1 (interval start) or 2 (start
+ * and the text position of the string's first row).  For measurement. */
+int bwtgpu_index_kmer_table(const bwtgpu_index *ix, uint32_t *k, uint32_t *entry_words);
 /* An index built on the device keeps, beside what make_fmi (seqindex.c:161-189)
  * produces, the whole suffix array, its inverse and the text (9.6 bytes per
  * base more) and uses them to finish searches and to locate in one lookup;
  * every index also holds a table of the SA intervals of all strings of k bases
- * (k = ceil(log4 n), at most 15, 4 bytes per string; BWT_MI355X_KMER=<k>
+ * (4 bytes per string and the smallest k with 4^k >= n for an index without
+ * its suffix array; 8 bytes -- the interval start and the text position of its
+ * first row, which is all a string that occurs once needs -- and the smallest k
+ * with 4^k >= 2n for one that keeps it; at most k = 16; BWT_MI355X_KMER=<k>
  * overrides), where
  * searches of longer reads start.  Results are the same with or without them.
  * This call frees all four and leaves the rank blocks and the sampled suffix

@@ -253,7 +253,10 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     monkeypatch.setenv("BWT_MI355X_KMER", str(k))
     full = gpu.build_index(text, n)
     lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    full.prepare_search()  # the table is made on first search: make it while the size is forced
+    lean.prepare_search()
     monkeypatch.delenv("BWT_MI355X_KMER")
+    assert full.kmer_table == ((k, 2) if k >= 2 else (0, 0)) and lean.kmer_table == ((k, 1) if k >= 2 else (0, 0))
     bases = synth.unpack(text, n)
     for m in (1, 4, 8, 9, 10, 11, 12, 16, 17, 23, 32, 33, 70):
         R = 3000
@@ -270,7 +273,7 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
             got[got == 0xFFFFFFFF] = -1
             np.testing.assert_array_equal(got, want, err_msg=f"{name} m={m}")
     loads, _, _ = full.search_loads(torch.from_numpy(reads.reshape(-1)).cuda(), 70, 3000)
-    assert loads["kmer_entries_8B"] == (3000 if k >= 2 else 0)
+    assert loads["kmer_entries"] == (3000 if k >= 2 else 0)
 
 
 @pytest.mark.parametrize("tail", ["CAAA", "TTTT", "GATTACA", "AAAAAAAA", "ACGT"])
@@ -289,7 +292,10 @@ def test_kmer_table_around_the_short_suffixes(oracle, gpu, k, tail, monkeypatch)
         monkeypatch.setenv("BWT_MI355X_KMER", str(k))
         full = gpu.build_index(text, n)
         lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+        full.prepare_search()  # the table is made on first search: make it while the size is forced
+        lean.prepare_search()
         monkeypatch.delenv("BWT_MI355X_KMER")
+        assert full.kmer_table == (k, 2) and lean.kmer_table == (k, 1)
         for m in (k, k + 1):
             R = 4 ** m
             x = np.arange(R, dtype=np.uint32)
@@ -311,6 +317,7 @@ def test_two_step_inverse_suffix_array(oracle, gpu, n, levels, monkeypatch):
     fo = oracle.make_fmi(text, n)
     monkeypatch.setenv("BWT_MI355X_ISA_TWO_STEP", levels)
     ix = gpu.build_index(text, n)
+    ix.prepare_search()  # the position records are made on first search: make them while the path is forced
     monkeypatch.delenv("BWT_MI355X_ISA_TWO_STEP")
     R, m = 20000, 60
     reads = _mutated_reads(synth.unpack(text, n), n, R, m, 77)

@@ -86,6 +86,9 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
             assert np.array_equal(G.to_numpy_u32(sa), sa_o), "SA"
             full = G.build_index_dev(t, n)
             lean = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+            if rng.integers(0, 4):  # mostly: the search arrays made now, under the forced sizes; else by the first search
+                full.prepare_search()
+                lean.prepare_search()
             assert full.endloc == fo.endloc and full.C == fo.C, "endloc/C"
             bwt, idxs = full.export()
             assert np.array_equal(bwt, fo.bwt) and np.array_equal(idxs, fo.idxs), "export"
