@@ -162,7 +162,7 @@ constexpr uint32_t kHistTilesPerGroup = 4;
 
 // LDS-privatised histogram of the next four bases of every suffix in a run of
 // tiles; counts go to the segment's counters when the run leaves the segment.
-// MODE 0: ids are implicit (level 0: the tile is a range of text positions);
+// Level 0 has a kernel of its own (k_part_hist0).
 // MODE 1: ids from src, bases from the text;
 // MODE 2: the bases are bits 23..16 of the word the previous level's scatter
 //         stored next to the id (its key started four bases earlier): no gather;
@@ -173,19 +173,15 @@ __global__ void __launch_bounds__(kPartThreads)
 k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
             const uint32_t *__restrict__ srckey, const Seg *__restrict__ segs,
             const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
-            const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts, int by_eighth) {
-  // by_eighth (level 0, one segment): counts are kept per eighth of the tiles,
-  // the share one XCD's scatter workgroups handle (see locate_tile), in slot
-  // `eighth` where a segment number goes otherwise.
+            const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
   __shared__ uint32_t hist[256];
   __shared__ TileInfo ti;
   hist[threadIdx.x] = 0;
   uint32_t cur_seg = 0xFFFFFFFFu;
-  const uint32_t per_xcd = (ctr->total_tiles + 7u) / 8u;
   for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
     const uint32_t tile = blockIdx.x * kHistTilesPerGroup + k;
     const bool live = locate_tile_at(tile, segs, tile_first, nsegs, ctr, &ti);
-    const uint32_t seg = !live ? 0xFFFFFFFFu : by_eighth ? tile / per_xcd : ti.seg;
+    const uint32_t seg = live ? ti.seg : 0xFFFFFFFFu;
     if (seg != cur_seg) {
       if (cur_seg != 0xFFFFFFFFu) {
         const uint32_t c = hist[threadIdx.x];
@@ -207,8 +203,7 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
         } else if (MODE == 3) {
           d = srckey[row0 + j] >> 24;
         } else {
-          const uint32_t id = MODE == 0 ? row0 + j : src[row0 + j];
-          d = key32(tb, (uint64_t)id + depth) >> 24;
+          d = key32(tb, (uint64_t)src[row0 + j] + depth) >> 24;
         }
         atomicAdd(&hist[d], 1u);
       }
@@ -312,20 +307,22 @@ __global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
 
 // Sharded build, level 0: keeps the counts of the digits in [dlo, dhi), clears
 // the others, and reports how many suffixes precede the range and fall in it.
+constexpr uint32_t kRangeSlots = 32, kRangeSlotStride = 16;  // partial sums, 128 bytes apart
+constexpr size_t kRangeBytes = (size_t)kRangeSlots * kRangeSlotStride * 8;
+
 __global__ void __launch_bounds__(256)
-k_restrict_level0(uint32_t *__restrict__ counts /* [8][256], one row per eighth of the tiles */,
-                  uint32_t dlo, uint32_t dhi, uint64_t *__restrict__ out /* [0] before, [1] inside */) {
-  __shared__ unsigned long long before, inside;
+k_restrict_level0(const uint32_t *__restrict__ counts /* [8][256], one row per eighth of the tiles */,
+                  uint32_t dlo, uint32_t dhi, const unsigned long long *__restrict__ before_slots,
+                  uint64_t *__restrict__ out /* [0] before, [1] inside */) {
+  // the histogram counted the digits of the range only, and how many positions lie before it
+  __shared__ unsigned long long inside, before;
   const uint32_t t = threadIdx.x;
-  if (t == 0) before = inside = 0;
+  if (t == 0) inside = before = 0;
   __syncthreads();
   uint32_t c = 0;
-  for (int e = 0; e < 8; ++e) {
-    c += counts[e * 256 + t];
-    if (t < dlo || t >= dhi) counts[e * 256 + t] = 0;
-  }
-  if (t < dlo) atomicAdd(&before, (unsigned long long)c);
-  else if (t < dhi) atomicAdd(&inside, (unsigned long long)c);
+  for (int e = 0; e < 8; ++e) c += counts[e * 256 + t];
+  if (t >= dlo && t < dhi && c) atomicAdd(&inside, (unsigned long long)c);
+  if (t < kRangeSlots && before_slots[t * kRangeSlotStride]) atomicAdd(&before, before_slots[t * kRangeSlotStride]);
   __syncthreads();
   if (t == 0) {
     out[0] = before;
@@ -336,24 +333,20 @@ k_restrict_level0(uint32_t *__restrict__ counts /* [8][256], one row per eighth 
 // Tile-local bucket order in LDS, then each bucket's run goes to the
 // segment's cursor for that bucket (one atomic per tile and bucket).  Order
 // inside a bucket is irrelevant at this stage.
-// IMPLICIT (level 0): ids are text positions, keys come from sequential text.
-// Otherwise the bucket of a suffix is read from the word the previous level
-// stored with it, and the word is passed on; fresh keys are gathered from the
-// text only when the stored words have run out of bases (see carried_word).
-template <bool IMPLICIT>
+// The bucket of a suffix is read from the word the previous level stored with
+// it, and the word is passed on; fresh keys are gathered from the text only when
+// the stored words have run out of bases (see carried_word).  Level 0 has a
+// kernel of its own (k_part_scatter0).
 __global__ void __launch_bounds__(kScatThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
                const uint32_t *__restrict__ srckey, uint32_t *__restrict__ dst,
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
                const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
                const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors,
-               const uint32_t *__restrict__ leafmask, int gather_all, int top_digit, uint32_t dlo,
-               uint32_t dhi) {
+               int gather_all, int top_digit) {
   // gather_all: the stored words have run out of bases, read fresh ones for every suffix.
   // top_digit: the source word starts at this level's depth (level 1).
-  // dlo, dhi (level 0 only): suffixes whose first digit lies outside [dlo, dhi)
-  // belong to another shard of the build and are dropped here
-  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4], lmask[8];
+  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4];
   __shared__ uint32_t ids[kPartTile];
   __shared__ uint32_t kv[kPartTile];
   __shared__ TileInfo ti;
@@ -364,37 +357,19 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
-  if (IMPLICIT) {
-    if (t < 8) lmask[t] = leafmask[(uint64_t)ti.seg * 8 + t];
-    __syncthreads();
-  }
   uint32_t id[kPartItems], key[kPartItems];
-  uint32_t mine = 0;  // bit i: item i is a suffix this launch places
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
     const uint32_t j = (uint32_t)i * kScatThreads + t;
     if (j < count) {
-      if (IMPLICIT) {
-        id[i] = row0 + j;
-        const uint32_t k32 = key32(tb, (uint64_t)id[i] + depth);
-        const uint32_t d = k32 >> 24;
-        if (d < dlo || d >= dhi) continue;
-        mine |= 1u << i;
-        atomicAdd(&hist[d], 1u);
-        const bool leaf = (lmask[d >> 5] >> (d & 31u)) & 1u;
-        key[i] = carried_word(tb, id[i], leaf ? k32 : key32(tb, (uint64_t)id[i] + kDigitBases));
-        id[i] = (d << 24) | j;  // the digit rides with the tile-local index: the word may not start with it
-      } else {
-        mine |= 1u << i;
-        id[i] = src[row0 + j];
-        const uint32_t old = srckey[row0 + j];
-        const uint32_t d = top_digit ? old >> 24 : (old >> 16) & 255u;
-        atomicAdd(&hist[d], 1u);
-        if (gather_all)
-          key[i] = (key32(tb, (uint64_t)id[i] + depth) & ~3u) | (old & 3u);
-        else
-          key[i] = top_digit ? old : ((old & ~3u) << 8) | (old & 3u);
-      }
+      id[i] = src[row0 + j];
+      const uint32_t old = srckey[row0 + j];
+      const uint32_t d = top_digit ? old >> 24 : (old >> 16) & 255u;
+      atomicAdd(&hist[d], 1u);
+      if (gather_all)
+        key[i] = (key32(tb, (uint64_t)id[i] + depth) & ~3u) | (old & 3u);
+      else
+        key[i] = top_digit ? old : ((old & ~3u) << 8) | (old & 3u);
     }
   }
   __syncthreads();
@@ -415,15 +390,13 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
     lstart[t] = pre + v - c;
-    // level 0 keeps one row of cursors per eighth of the tiles, i.e. per XCD
-    const uint64_t cursor_row = IMPLICIT ? (uint64_t)(blockIdx.x & 7u) : (uint64_t)ti.seg;
-    gbase[t] = c ? atomicAdd(&cursors[cursor_row * 256 + t], c) : 0u;
+    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kPartItems; ++i) {
-    if ((mine >> i) & 1u) {
-      const uint32_t d = IMPLICIT ? id[i] >> 24 : key[i] >> 24;
+    if ((uint32_t)i * kScatThreads + t < count) {
+      const uint32_t d = key[i] >> 24;
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
       kv[p] = key[i];
@@ -432,11 +405,180 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
   for (uint32_t j = t; j < placed; j += kScatThreads) {
-    const uint32_t k = kv[j], v = ids[j];
-    const uint32_t d = IMPLICIT ? v >> 24 : k >> 24;
-    const uint32_t pos = gbase[d] + (j - lstart[d]);
-    dst[pos] = IMPLICIT ? row0 + (v & 0xFFFFFFu) : v;
+    const uint32_t k = kv[j];
+    const uint32_t pos = gbase[k >> 24] + (j - lstart[k >> 24]);
+    dst[pos] = ids[j];
     dstkey[pos] = k;
+  }
+}
+
+// ---- level 0 ---------------------------------------------------------------
+//
+// Level 0 sorts text positions themselves: a tile is 8192 consecutive positions,
+// so a thread can take 16 (or 32) consecutive ones and read their bases out of a
+// register window of three (or four) text words instead of loading a window per
+// position.  In a sharded build most positions are looked at only to be dropped
+// (their first four bases belong to another rank), which is then nearly free.
+
+// 16 bases starting `o` bases (0..31) into the 48 bases of the words a, b, c
+__device__ __forceinline__ uint32_t window16(uint32_t a, uint32_t b, uint32_t c, uint32_t o) {
+  const uint64_t ab = ((uint64_t)a << 32) | b, bc = ((uint64_t)b << 32) | c;
+  return o < 16 ? (uint32_t)((ab << (2 * o)) >> 32) : (uint32_t)((bc << (2 * (o - 16))) >> 32);
+}
+
+// Counts of the leading four bases of every position, per eighth of the tiles (see
+// k_part_classify's by_eighth), restricted to digits in [dlo, dhi); the positions
+// whose digit lies below dlo are only counted, into the slots of range_counts.
+__global__ void __launch_bounds__(kPartThreads)
+k_part_hist0(const uint32_t *__restrict__ tb, uint32_t n, const Counters *__restrict__ ctr,
+             uint32_t *__restrict__ seg_counts, uint32_t dlo, uint32_t dhi,
+             unsigned long long *__restrict__ range_counts) {
+  __shared__ uint32_t hist[256];
+  const uint32_t t = threadIdx.x;
+  hist[t] = 0;
+  const uint32_t total_tiles = ctr->total_tiles, per_xcd = (total_tiles + 7u) / 8u;
+  uint32_t cur = 0xFFFFFFFFu, before = 0;
+  __syncthreads();
+  for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
+    const uint32_t tile = blockIdx.x * kHistTilesPerGroup + k;
+    if (tile >= total_tiles) break;  // uniform
+    const uint32_t eighth = tile / per_xcd;
+    if (eighth != cur) {
+      if (cur != 0xFFFFFFFFu) {
+        const uint32_t c = hist[t];
+        if (c) atomicAdd(&seg_counts[(uint64_t)cur * 256 + t], c);
+        hist[t] = 0;
+      }
+      cur = eighth;
+      __syncthreads();
+    }
+    const uint32_t row0 = tile * (uint32_t)kPartTile;
+    const uint32_t count = n - row0 < (uint32_t)kPartTile ? n - row0 : (uint32_t)kPartTile;
+    // kHistItems = 32 consecutive positions per thread: two words and two of lookahead
+    const uint64_t w = ((uint64_t)row0 >> 4) + 2ull * t;
+    const uint32_t p0 = 32u * t;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    if (p0 < count) {  // the text is padded by a few words only
+      w0 = tb[w];
+      w1 = tb[w + 1];
+      w2 = tb[w + 2];
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 32; ++q) {
+      if (p0 + q < count) {
+        const uint32_t d = window16(w0, w1, w2, q) >> 24;
+        if (d >= dlo && d < dhi) atomicAdd(&hist[d], 1u);
+        else before += d < dlo ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+  }
+  if (cur != 0xFFFFFFFFu) {
+    const uint32_t c = hist[t];
+    if (c) atomicAdd(&seg_counts[(uint64_t)cur * 256 + t], c);
+  }
+  if (range_counts) {
+    // one atomic per workgroup, spread over kRangeSlots cache lines: every workgroup
+    // of the launch adding to one address would take longer than the counting
+    __syncthreads();
+    if (t == 0) hist[0] = 0;
+    __syncthreads();
+    for (int off = 32; off; off >>= 1) before += __shfl_down(before, off, 64);
+    if ((t & 63u) == 0 && before) atomicAdd(&hist[0], before);
+    __syncthreads();
+    if (t == 0 && hist[0])
+      atomicAdd(&range_counts[(blockIdx.x % kRangeSlots) * kRangeSlotStride], (unsigned long long)hist[0]);
+  }
+}
+
+// Level-0 scatter: as k_part_scatter, for a tile of 8192 consecutive positions.
+// A suffix that goes on to level 1 carries bases 4..18 (its digit is implied by
+// its bucket), one that ends in a level-0 leaf bases 0..14; both with the base
+// before it.  Positions whose digit lies outside [dlo, dhi) are dropped.
+__global__ void __launch_bounds__(kScatThreads)
+k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restrict__ dst,
+                uint32_t *__restrict__ dstkey, const Counters *__restrict__ ctr,
+                uint32_t *__restrict__ cursors /* [8][256]: one row per eighth of the tiles */,
+                const uint32_t *__restrict__ leafmask, uint32_t dlo, uint32_t dhi) {
+  __shared__ uint32_t hist[256], lstart[256], gbase[256], fill[256], wsum[4], lmask[8];
+  __shared__ uint32_t ids[kPartTile];
+  __shared__ uint32_t kv[kPartTile];
+  const uint32_t t = threadIdx.x;
+  if (t < 256) {
+    hist[t] = 0;
+    fill[t] = 0;
+  }
+  if (t < 8) lmask[t] = leafmask[t];
+  // the x-th eighth of the tiles goes to XCD x (see locate_tile)
+  const uint32_t total_tiles = ctr->total_tiles, per_xcd = (total_tiles + 7u) / 8u;
+  const uint32_t seq = blockIdx.x >> 3;
+  const uint32_t tile = (blockIdx.x & 7u) * per_xcd + seq;
+  if (seq >= per_xcd || tile >= total_tiles) return;  // uniform
+  const uint32_t row0 = tile * (uint32_t)kPartTile;
+  const uint32_t count = n - row0 < (uint32_t)kPartTile ? n - row0 : (uint32_t)kPartTile;
+  __syncthreads();
+  // 16 consecutive positions per thread: their word, the base before it, two words of lookahead
+  const uint64_t w = ((uint64_t)row0 >> 4) + t;
+  const uint32_t p0 = 16u * t;
+  uint32_t w0 = 0, w1 = 0, w2 = 0, prev = 0;
+  if (p0 < count) {  // the text is padded by a few words only
+    w0 = tb[w];
+    w1 = tb[w + 1];
+    w2 = tb[w + 2];
+    prev = w ? tb[w - 1] & 3u : 0u;  // base 15 of the word before
+  }
+  uint32_t kept = 0;  // bit q: position p0 + q is this shard's
+#pragma unroll
+  for (uint32_t q = 0; q < 16; ++q) {
+    if (p0 + q < count) {
+      const uint32_t d = window16(w0, w1, w2, q) >> 24;
+      if (d >= dlo && d < dhi) {
+        kept |= 1u << q;
+        atomicAdd(&hist[d], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  uint32_t c = 0, v = 0;
+  if (t < 256) {
+    c = hist[t];
+    v = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+  }
+  __syncthreads();
+  if (t < 256) {
+    uint32_t pre = 0;
+    for (uint32_t q = 0; q < wave; ++q) pre += wsum[q];
+    lstart[t] = pre + v - c;
+    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)(blockIdx.x & 7u) * 256 + t], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t q = 0; q < 16; ++q) {
+    if ((kept >> q) & 1u) {
+      const uint32_t k32 = window16(w0, w1, w2, q);
+      const uint32_t d = k32 >> 24;
+      const bool leaf = (lmask[d >> 5] >> (d & 31u)) & 1u;
+      const uint32_t key = leaf ? k32 : window16(w0, w1, w2, q + 4);
+      const uint32_t bw = q ? (w0 >> (32u - 2u * q)) & 3u : prev;  // the base before position p0 + q
+      const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
+      ids[p] = (d << 24) | (p0 + q);
+      kv[p] = (key & ~3u) | ((row0 + p0 + q) ? bw : 0u);
+    }
+  }
+  __syncthreads();
+  const uint32_t placed = lstart[255] + hist[255];
+  for (uint32_t j = t; j < placed; j += kScatThreads) {
+    const uint32_t id = ids[j];
+    const uint32_t d = id >> 24;
+    const uint32_t pos = gbase[d] + (j - lstart[d]);
+    dst[pos] = row0 + (id & 0xFFFFFFu);
+    dstkey[pos] = kv[j];
   }
 }
 
@@ -1097,7 +1239,7 @@ static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0,
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, ctr, scanws, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, ctr, scanws, range, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -1128,6 +1270,7 @@ static Layout layout_for(uint32_t n) {
   L.leaf_ties = take((size_t)L.leaf_cap);
   L.ctr = take(sizeof(Counters));
   L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
+  L.range = take(kRangeBytes + 16);
   L.end = off;
   return L;
 }
@@ -1227,17 +1370,19 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     const unsigned tile_bound = (unsigned)(((uint64_t)n / kPartTile + nsegs + 1 + 7) / 8 * 8);  // eighths, see locate_tile
     const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
     const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
+    unsigned long long *d_range = reinterpret_cast<unsigned long long *>(ws + L.range);
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_hist", k_part_hist<0>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 1);
+      if (range) BWT_HIP(hipMemsetAsync(d_range, 0, kRangeBytes + 16, s));
+      BWT_LAUNCH("sa_part_hist", k_part_hist0, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, n, ctr, counts, dlo,
+                 dhi, range ? d_range : (unsigned long long *)nullptr);
     } else if (levels == 1) {
       // level 0 stored words that start with this level's four bases
       BWT_LAUNCH("sa_part_hist", k_part_hist<3>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 0);
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     } else {
       // the word stored by the previous level holds this level's four bases in its second byte
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts, 0);
+                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
     }
     // Without a gather a suffix that ends in a leaf keeps bases [depth, reach) as
     // its sort key, and one that goes on needs the next level's digit, bases
@@ -1245,10 +1390,10 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     const bool gather_all = !implicit && (reach < depth + 11 || reach < depth + 2 * kDigitBases);
     const uint32_t leaf_keybases = (implicit || gather_all) ? kLeafKeyBases : reach - depth;
     if (range && depth == 0) {
-      // rows of other shards leave the picture here; the scan workspace is idle
-      uint64_t *d_out = reinterpret_cast<uint64_t *>(scanws);
+      // rows of other shards leave the picture here
+      uint64_t *d_out = reinterpret_cast<uint64_t *>(d_range) + kRangeSlots * kRangeSlotStride;
       uint64_t h_out[2] = {0, 0};
-      BWT_LAUNCH("sa_restrict_level0", k_restrict_level0, dim3(1), dim3(256), 0, s, counts, dlo, dhi, d_out);
+      BWT_LAUNCH("sa_restrict_level0", k_restrict_level0, dim3(1), dim3(256), 0, s, counts, dlo, dhi, d_range, d_out);
       BWT_HIP(hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, s));
       BWT_HIP(hipStreamSynchronize(s));
       range->row_begin = 1 + h_out[0];
@@ -1265,14 +1410,13 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
                L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0);
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter<true>, dim3(tile_bound), dim3(kScatThreads), 0, s, tb,
-                 src, srckey, dst, dstkey, segs[cur], tile_first, nsegs, depth, ctr, counts, leafmask, 1, 0, dlo,
-                 dhi);
+      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScatThreads), 0, s, tb, n, dst,
+                 dstkey, ctr, counts, leafmask, dlo, dhi);
       reach = kDigitBases + kLeafKeyBases;  // suffixes that go on carry bases 4..18
     } else {
-      BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter<false>,
+      BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter,
                  dim3(tile_bound), dim3(kScatThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
-                 nsegs, depth, ctr, counts, leafmask, gather_all ? 1 : 0, levels == 1 ? 1 : 0, 0u, 256u);
+                 nsegs, depth, ctr, counts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
       if (gather_all) reach = depth + kLeafKeyBases;
     }
     BWT_CHECK_LAUNCH();

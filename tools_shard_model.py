@@ -61,6 +61,11 @@ for n in [int(x) for x in (sys.argv[1:] or ["250000000", "3100000000"])]:
         del packed
         G.build_index_from_shards(t, n, parts).close()
         ms_asm, ixs = timed(lambda: G.build_index_from_shards(t, n, parts), 1)
+        if world == 8:
+            G.timing_enable(True); G.timing_reset()
+            G.build_index_from_shards(t, n, parts).close()
+            rep = G.timing_report(); G.timing_enable(False)
+            print(n, "assemble kernels", {k: round(v[1], 3) for k, v in sorted(rep.items()) if v[1] > 0.005}, flush=True)
         ms_att, _ = timed(lambda: G.check(lib.bwtgpu_index_attach_sa(ixs.h, t.data_ptr(), sa.data_ptr(), None)), 1)
         ok = all(v == 0 for v in ixs.certify(t).values())
         ixs.close()
