@@ -34,10 +34,22 @@ struct ShardTable {
   uint64_t bw2_offset[kMaxShards];     // where shard g's packed symbols start in the gathered buffer
 };
 
-// One wave per eight 64-base blocks: lane k holds BWT position 64 b + k, whose
-// row is one further along once past the $ row (histsortcomp.c:238-245); the
-// row's symbol comes from the shard that holds the row, row 0 (the empty
-// suffix) is preceded by the last base of the text.
+// even bits of a 16-bit value, packed into 8
+__device__ __forceinline__ uint32_t even_bits8(uint32_t x) {
+  x &= 0x5555u;
+  x = (x | (x >> 1)) & 0x3333u;
+  x = (x | (x >> 2)) & 0x0F0Fu;
+  return (x | (x >> 4)) & 0xFFu;
+}
+
+// One wave per eight 64-base blocks.  BWT position p is the symbol of row p,
+// one further along once past the $ row (histsortcomp.c:238-245); the row's
+// symbol comes from the shard that holds the row, row 0 (the empty suffix) is
+// preceded by the last base of the text.
+// Nearly every wave finds its 512 rows in one shard, on one side of the $ row:
+// then lane k takes eight neighbouring symbols out of three bytes of that shard
+// and the planes of a block are eight lanes' bytes side by side.  The other
+// waves look every row up on its own.
 __global__ void __launch_bounds__(256)
 k_planes_from_shards(const uint8_t *__restrict__ text, const uint8_t *__restrict__ bw2, ShardTable tab, uint32_t n,
                      uint32_t endloc, IndexBlock *__restrict__ blocks, uint64_t nblocks) {
@@ -50,6 +62,35 @@ k_planes_from_shards(const uint8_t *__restrict__ text, const uint8_t *__restrict
   const uint64_t b0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kPer;
   const uint32_t lane = threadIdx.x & 63u;
   if (b0 >= nblocks) return;  // wave-uniform
+  const uint64_t p_first = b0 * 64, p_end = p_first + 64 * kPer;
+  if (p_end <= n && (endloc <= p_first || endloc >= p_end)) {
+    const uint64_t r_first = p_first + (endloc <= p_first ? 1 : 0);  // all of them shifted, or none
+    uint32_t lo = 0, hi = tab.nshards;  // begin[lo] <= r_first < begin[hi]; the same in every lane
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (begin[mid] <= r_first) lo = mid; else hi = mid;
+    }
+    if (r_first >= 1 && r_first + 64 * kPer <= begin[lo + 1]) {
+      const uint32_t j = (uint32_t)(r_first - begin[lo]) + 8u * lane;
+      const uint8_t *at = bw2 + offset[lo] + (j >> 2);
+      uint32_t v = (uint32_t)at[0] | ((uint32_t)at[1] << 8);
+      if (j & 3u) v |= (uint32_t)at[2] << 16;  // eight symbols from a byte boundary take two bytes
+      v >>= 2 * (j & 3u);
+      // lane 8 m + i holds byte i of block m's planes
+      uint64_t plo = (uint64_t)even_bits8(v) << (8 * (lane & 7u));
+      uint64_t phi = (uint64_t)even_bits8(v >> 1) << (8 * (lane & 7u));
+#pragma unroll
+      for (int off = 1; off < 8; off <<= 1) {
+        plo |= __shfl_xor(plo, off, 64);
+        phi |= __shfl_xor(phi, off, 64);
+      }
+      if ((lane & 7u) == 0) {
+        blocks[b0 + (lane >> 3)].lo = plo;
+        blocks[b0 + (lane >> 3)].hi = phi;
+      }
+      return;
+    }
+  }
   uint32_t base[kPer];
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
