@@ -238,7 +238,9 @@ int search_host_streamed(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t
 void pinned_release_idle();
 
 // index.hip
-int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s);
+// `readback`: 8 words of pinned host memory for C[] to land in, or null (the copy
+// into pageable memory then waits for the stream by itself).  Waits for `s`.
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback = nullptr);
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known
 // Makes the search-only arrays an index still lacks (see bwtgpu_index); safe to
 // call from several threads, returns at once when there is nothing to do, and
@@ -263,7 +265,23 @@ struct SaExtras {
   // samples[i]), or null; out: whether all of them were written
   uint32_t *samples = nullptr;
   bool samples_done = false;
+  // in: 16 words of pinned host memory, or null.  With it a whole-text build
+  // does not wait to learn whether the leaf sort left rows tied: it hands out
+  // the by-products as if none were, queues the copy of its counters into
+  // these words and sets `pending`; the caller goes on queueing work on the
+  // same stream and calls sa_build_settle after its next synchronisation.
+  uint32_t *readback = nullptr;
+  bool pending = false;
+  struct {  // what sa_build_settle needs of the workspace
+    uint32_t *d_sa = nullptr, *ghead = nullptr, *flags = nullptr;
+    void *leaves = nullptr, *leaf_ties = nullptr, *ctr = nullptr;
+    uint32_t n = 0, nleaves = 0;
+  } later;
 };
+// 0: no row was left tied, the by-products stand.  1: tied rows were sorted by
+// prefix doubling just now (the stream has been waited for); the suffix array is
+// final, the by-products are not to be used.  Negative: error.
+int sa_build_settle(SaExtras *extras, hipStream_t s);
 int sa_build_impl(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, void *d_ws,
                   size_t ws_bytes, hipStream_t s, SaExtras *extras);
 // After a build: a part of its workspace that no by-product lives in, at

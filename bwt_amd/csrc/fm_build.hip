@@ -349,10 +349,42 @@ struct BuildCache;
 static std::mutex g_caches_mu;
 static std::vector<BuildCache *> g_caches;
 
+// A build reads a few words back from the device (the sort's counters, the $
+// row, C[]).  Copied into pageable memory each of them waits for the stream;
+// copied into pinned memory they all ride on the one wait at the end.  One
+// pinned page for the process, a 64-word slot of it per building thread (a
+// thread beyond the 16th builds with pageable copies); the page is never freed.
+static std::mutex g_readback_mu;
+static uint32_t *g_readback_page = nullptr;
+static uint32_t g_readback_free = 0xFFFFu;
+
+static uint32_t *readback_acquire(int *slot) {
+  std::lock_guard<std::mutex> lock(g_readback_mu);
+  if (!g_readback_page) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, 4096, hipHostMallocPortable) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_readback_page = static_cast<uint32_t *>(p);
+  }
+  if (!g_readback_free) return nullptr;
+  *slot = __builtin_ctz(g_readback_free);
+  g_readback_free &= g_readback_free - 1;
+  return g_readback_page + 64 * *slot;
+}
+
+static void readback_release(int slot) {
+  std::lock_guard<std::mutex> lock(g_readback_mu);
+  g_readback_free |= 1u << slot;
+}
+
 struct BuildCache {
   int device = -1;
   void *sa = nullptr, *ws = nullptr, *small = nullptr;
   size_t sa_bytes = 0, ws_bytes = 0;
+  uint32_t *readback = nullptr;  // this thread's slot of the pinned page, or null
+  int readback_slot = -1;
   std::mutex busy;  // held by the owning thread for the length of a build
   BuildCache() {
     std::lock_guard<std::mutex> lock(g_caches_mu);
@@ -367,6 +399,7 @@ struct BuildCache {
           break;
         }
     }
+    if (readback_slot >= 0) readback_release(readback_slot);
     // no HIP call here: the main thread gets here after the runtime may have shut down
     pool_adopt_idle(sa, sa_bytes, device);
     pool_adopt_idle(ws, ws_bytes, device);
@@ -389,6 +422,7 @@ static int cache_reserve(size_t sa_bytes, size_t ws_bytes) {
   if (g_cache.device != dev) g_cache.release();
   g_cache.device = dev;
   if (!g_cache.small) BWT_HIP(hipMalloc(&g_cache.small, 4096));
+  if (!g_cache.readback) g_cache.readback = readback_acquire(&g_cache.readback_slot);
   if (g_cache.sa_bytes < sa_bytes) {
     if (g_cache.sa) (void)hipFree(g_cache.sa);
     g_cache.sa = nullptr;
@@ -428,7 +462,8 @@ static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
 // ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
 // rows 1..n and *d_endloc then already holds the $ row.
 static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
-                      const uint8_t *bw, uint32_t *d_endloc, bool have_samples, hipStream_t s) {
+                      const uint8_t *bw, uint32_t *d_endloc, bool have_samples, hipStream_t s,
+                      uint32_t *readback = nullptr /* 16 pinned words, or null */) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
     BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows,
@@ -448,9 +483,11 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(readback ? readback + 8 : &ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
-  BWT_TRY(index_finish_from_planes(ix, s));  // synchronises the stream
+  BWT_TRY(index_finish_from_planes(ix, s, readback));  // synchronises the stream
+  if (readback) ix->endloc = readback[8];
   if (ix->endloc > n) return set_error(kErrInternal, "no suffix-array row holds suffix 0");
   // what make_fmi produces is complete; the search-only arrays wait for the first search
   index_defer_search_arrays(ix);
@@ -508,10 +545,21 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
   SaExtras extras;
   extras.samples = ix->d_idxs;
+  uint32_t *readback = g_cache.readback;  // words 0..15: the sort's counters; 16..31: emit_index
+  extras.readback = readback;
   rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
     if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
-    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, extras.samples_done, s);
+    const bool assumed = extras.pending;  // ... that the leaf sort left no rows tied
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, extras.samples_done, s,
+                    readback ? readback + 16 : nullptr);
+    if (assumed) {
+      if (rc != kOk) (void)hipStreamSynchronize(s);  // emit_index waits only when all went well
+      const int settled = sa_build_settle(&extras, s);
+      if (settled < 0) rc = settled;
+      else if (settled > 0)  // it had: the rows have changed, emit again from the final suffix array
+        rc = emit_index(ix, d_text, n, d_sa, nullptr, d_endloc, false, s, readback ? readback + 16 : nullptr);
+    }
   }
   if (rc != kOk) {
     bwtgpu_index_free(ix);

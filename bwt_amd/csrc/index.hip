@@ -563,7 +563,7 @@ int index_alloc(bwtgpu_index **out, uint32_t n) {
 }
 
 // Planes of every block are in place; computes occ[] and C[].
-int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback) {
   const uint64_t nb = ix->nblocks;
   const uint32_t ntiles = (uint32_t)div_up(nb, kTileBlocks);
   uint4 *d_tiles = nullptr;
@@ -578,9 +578,12 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s) {
   BWT_LAUNCH("rank_build_sym", k_build_sym, dim3((unsigned)div_up(ix->nsym, 256)), dim3(256), 0, s,
              ix->d_blocks, nb, ix->n, ix->d_sym, ix->nsym);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess) e = hipMemcpyAsync(ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(readback ? readback : ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) (void)hipDeviceSynchronize();
+  else if (readback)
+    for (int c = 0; c < 5; ++c) ix->C[c] = readback[c];
   pool_free(d_tiles);
   if (e != hipSuccess) return set_error(kErrHip, "rank table build: %s", hipGetErrorString(e));
   if (ix->C[4] != ix->n + 1)

@@ -19,6 +19,8 @@
 // end-of-text symbol smaller than A (histsortcomp.c:54-64 puts the suffix that
 // ends first).  Padding the text with A (zeros) and breaking exact ties by
 // "larger start first" gives the same order, so keys never need a fifth symbol.
+#include <cstring>
+
 #include "common.hpp"
 #include "radix_sort.hpp"
 #include "scan.hpp"
@@ -56,6 +58,7 @@ struct Counters {
   uint32_t total_tiles;
   uint32_t active;      // doubling: rows still in groups
   uint32_t endloc;      // SA row whose suffix starts at 0 (the $ of the BWT)
+  uint32_t ncur;        // segments of the level being partitioned (k_begin_level)
 };
 
 // ---- text -------------------------------------------------------------
@@ -127,13 +130,13 @@ struct TileInfo {
 };
 
 __device__ __forceinline__ bool locate_tile_at(uint32_t tile, const Seg *segs,
-                                               const uint32_t *tile_first, uint32_t nsegs,
-                                               const Counters *ctr, TileInfo *sh) {
+                                               const uint32_t *tile_first, const Counters *ctr,
+                                               TileInfo *sh) {
   if (threadIdx.x == 0) {
     if (tile >= ctr->total_tiles) {
       sh->count = 0;
     } else {
-      const uint32_t s = find_segment(tile_first, nsegs, tile);
+      const uint32_t s = find_segment(tile_first, ctr->ncur, tile);
       const Seg sg = segs[s];
       const uint32_t off = (tile - tile_first[s]) * (uint32_t)kPartTile;
       sh->seg = s;
@@ -151,11 +154,11 @@ __device__ __forceinline__ bool locate_tile_at(uint32_t tile, const Seg *segs,
 // keeps the runs that land next to each other in a bucket (consecutive tiles of
 // one segment) in one L2, where partial lines merge before they are written back.
 __device__ __forceinline__ bool locate_tile(const Seg *segs, const uint32_t *tile_first,
-                                            uint32_t nsegs, const Counters *ctr, TileInfo *sh) {
+                                            const Counters *ctr, TileInfo *sh) {
   const uint32_t per_xcd = (ctr->total_tiles + 7u) / 8u;
   const uint32_t seq = blockIdx.x >> 3;
   const uint32_t tile = seq < per_xcd ? (blockIdx.x & 7u) * per_xcd + seq : 0xFFFFFFFFu;
-  return locate_tile_at(tile, segs, tile_first, nsegs, ctr, sh);
+  return locate_tile_at(tile, segs, tile_first, ctr, sh);
 }
 
 constexpr uint32_t kHistTilesPerGroup = 4;
@@ -172,7 +175,7 @@ template <int MODE>
 __global__ void __launch_bounds__(kPartThreads)
 k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
             const uint32_t *__restrict__ srckey, const Seg *__restrict__ segs,
-            const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
+            const uint32_t *__restrict__ tile_first, uint32_t depth,
             const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
   __shared__ uint32_t hist[256];
   __shared__ TileInfo ti;
@@ -180,7 +183,7 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
   uint32_t cur_seg = 0xFFFFFFFFu;
   for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
     const uint32_t tile = blockIdx.x * kHistTilesPerGroup + k;
-    const bool live = locate_tile_at(tile, segs, tile_first, nsegs, ctr, &ti);
+    const bool live = locate_tile_at(tile, segs, tile_first, ctr, &ti);
     const uint32_t seg = live ? ti.seg : 0xFFFFFFFFu;
     if (seg != cur_seg) {
       if (cur_seg != 0xFFFFFFFFu) {
@@ -230,6 +233,7 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   // inside every child, so that what one XCD scatters lies together.
   __shared__ uint32_t sizes[256], starts[256], wsum[4];
   const uint32_t s = blockIdx.x, t = threadIdx.x;
+  if (s >= ctr->ncur) return;  // the grid covers the most segments this level can have
   const Seg sg = segs[s];
   uint32_t c = 0;
   if (by_eighth) {
@@ -299,14 +303,61 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   if (t < ns && sbase + t < next_cap) next_segs[sbase + t] = Seg{starts[sidx[t]], sizes[sidx[t]]};
 }
 
-__global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t nsegs,
-                                  uint32_t *__restrict__ tiles) {
-  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s < nsegs) tiles[s] = (segs[s].size + kPartTile - 1) / kPartTile;
+// The segments the level before emitted become this level's.  `bound` is what
+// the launches of this level are sized for: the exact count when the host has
+// read it, else the most a level of that depth can have -- the host then goes on
+// without waiting for the count.
+__global__ void k_begin_level(Counters *__restrict__ ctr, uint32_t bound) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t have = ctr->nnext;
+    ctr->ncur = have < bound ? have : bound;  // more only after an overflow, which is reported
+    ctr->nnext = 0;
+  }
 }
 
-// Sharded build, level 0: keeps the counts of the digits in [dlo, dhi), clears
-// the others, and reports how many suffixes precede the range and fall in it.
+// k_begin_level, the tiles of every segment and their exclusive scan in one
+// workgroup, for levels of at most 1024 segments (the first two of any text):
+// five launches less than the general path below.
+__global__ void __launch_bounds__(1024)
+k_begin_level_small(Counters *__restrict__ ctr, uint32_t bound, const Seg *__restrict__ segs,
+                    uint32_t *__restrict__ tile_first) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t ncur;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  if (t == 0) {
+    const uint32_t have = ctr->nnext;
+    ncur = have < bound ? have : bound;
+  }
+  __syncthreads();
+  const uint32_t c = t < ncur ? (segs[t].size + kPartTile - 1) / kPartTile : 0u;
+  uint32_t v = c;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0, total = 0;
+  for (uint32_t w = 0; w < 16; ++w) {
+    if (w < wave) pre += wsum[w];
+    total += wsum[w];
+  }
+  if (t < bound) tile_first[t] = pre + v - c;
+  if (t == 0) {
+    ctr->ncur = ncur;
+    ctr->nnext = 0;
+    ctr->total_tiles = total;
+  }
+}
+
+__global__ void k_seg_tile_counts(const Seg *__restrict__ segs, uint32_t bound, const Counters *__restrict__ ctr,
+                                  uint32_t *__restrict__ tiles) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < bound) tiles[s] = s < ctr->ncur ? (segs[s].size + kPartTile - 1) / kPartTile : 0u;
+}
+
+// Sharded build, level 0: how many suffixes precede the digit range [dlo, dhi)
+// and how many fall in it.
 constexpr uint32_t kRangeSlots = 32, kRangeSlotStride = 16;  // partial sums, 128 bytes apart
 constexpr size_t kRangeBytes = (size_t)kRangeSlots * kRangeSlotStride * 8;
 
@@ -341,7 +392,7 @@ __global__ void __launch_bounds__(kScatThreads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
                const uint32_t *__restrict__ srckey, uint32_t *__restrict__ dst,
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
-               const uint32_t *__restrict__ tile_first, uint32_t nsegs, uint32_t depth,
+               const uint32_t *__restrict__ tile_first, uint32_t depth,
                const Counters *__restrict__ ctr, uint32_t *__restrict__ cursors,
                int gather_all, int top_digit) {
   // gather_all: the stored words have run out of bases, read fresh ones for every suffix.
@@ -355,7 +406,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     hist[t] = 0;
     fill[t] = 0;
   }
-  if (!locate_tile(segs, tile_first, nsegs, ctr, &ti)) return;
+  if (!locate_tile(segs, tile_first, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
   uint32_t id[kPartItems], key[kPartItems];
 #pragma unroll
@@ -1299,6 +1350,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     extras->bw = nullptr;
     extras->endloc = nullptr;
     extras->samples_done = false;
+    extras->pending = false;
   }
   if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
   if (range && (range->dlo >= range->dhi || range->dhi > 256))
@@ -1350,8 +1402,19 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   } else {
     const Seg whole = {0, n};
     BWT_HIP(hipMemcpyAsync(segs[0], &whole, sizeof whole, hipMemcpyHostToDevice, s));
+    const uint32_t one = 1;
+    BWT_HIP(hipMemcpyAsync(&ctr->nnext, &one, 4, hipMemcpyHostToDevice, s));
     nsegs = 1;
   }
+  // A text without long repeats is through after the first level whose buckets
+  // hold kLeafMax suffixes on average.  Up to that level the host does not wait
+  // to learn how many segments a level left: it sizes the next level's launches
+  // for the most there can be (256 per segment, and no more than fit the rows)
+  // and the kernels take the count from the device.  After it, every level is
+  // read back as before.
+  int expected_levels = 1;
+  for (uint64_t per = (uint64_t)n >> 8; per > kLeafMax; per >>= 8) ++expected_levels;
+  bool exact = true;  // nsegs is the count the device holds, not a bound on it
   int levels = 0;
   uint32_t reach = 0;  // the words stored with the ids hold the text up to this base (exclusive)
   while (nsegs > 0 && depth < kMaxDepth) {
@@ -1359,14 +1422,18 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     const uint32_t *src = src_id == kSrcA ? bufA : src_id == kSrcB ? bufB : nullptr;
     uint32_t *dst = dst_id == kSrcA ? bufA : bufB;
     uint32_t *dstkey = dst_id == kSrcA ? keyA : keyB;
-    // tiles of this level's segments
-    BWT_LAUNCH("sa_seg_tiles", k_seg_tile_counts, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s,
-               segs[cur], nsegs, tile_first);
-    BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tile_first, tile_first, nsegs, &ctr->total_tiles,
-                            scanws, scanws_bytes, s));
+    // this level's segments and where the tiles of each begin
+    if (nsegs <= 1024) {
+      BWT_LAUNCH("sa_begin_level", k_begin_level_small, dim3(1), dim3(1024), 0, s, ctr, nsegs, segs[cur], tile_first);
+    } else {
+      BWT_LAUNCH("sa_begin_level", k_begin_level, dim3(1), dim3(64), 0, s, ctr, nsegs);
+      BWT_LAUNCH("sa_seg_tiles", k_seg_tile_counts, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s,
+                 segs[cur], nsegs, ctr, tile_first);
+      BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tile_first, tile_first, nsegs, &ctr->total_tiles,
+                              scanws, scanws_bytes, s));
+    }
     const bool implicit = src_id == kSrcImplicit;  // level 0: one segment, counts per eighth of its tiles
     BWT_HIP(hipMemsetAsync(counts, 0, (size_t)(implicit ? 8 : nsegs) * 256 * 4, s));
-    BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
     const unsigned tile_bound = (unsigned)(((uint64_t)n / kPartTile + nsegs + 1 + 7) / 8 * 8);  // eighths, see locate_tile
     const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
     const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
@@ -1378,11 +1445,11 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     } else if (levels == 1) {
       // level 0 stored words that start with this level's four bases
       BWT_LAUNCH("sa_part_hist", k_part_hist<3>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, depth, ctr, counts);
     } else {
       // the word stored by the previous level holds this level's four bases in its second byte
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, nsegs, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, depth, ctr, counts);
     }
     // Without a gather a suffix that ends in a leaf keeps bases [depth, reach) as
     // its sort key, and one that goes on needs the next level's digit, bases
@@ -1416,20 +1483,29 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     } else {
       BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter,
                  dim3(tile_bound), dim3(kScatThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
-                 nsegs, depth, ctr, counts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
+                 depth, ctr, counts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
       if (gather_all) reach = depth + kLeafKeyBases;
     }
     BWT_CHECK_LAUNCH();
-    BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
-    BWT_HIP(hipStreamSynchronize(s));
-    if (h_ctr.overflow) return set_error(kErrInternal, "SA build: bucket list overflow at depth %u", depth);
-    nsegs = h_ctr.nnext;
-    nleaves_host = h_ctr.nleaves;
     cur ^= 1;
     src_id = dst_id;
     depth += kDigitBases;
     ++levels;
+    if (levels < expected_levels && depth < kMaxDepth) {
+      // go on without the count: 256 children per segment at most, each of more than kLeafMax rows
+      const uint64_t most = (uint64_t)nsegs * 256;
+      nsegs = (uint32_t)(most < L.seg_cap ? most : L.seg_cap);
+      exact = false;
+      continue;
+    }
+    BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+    BWT_HIP(hipStreamSynchronize(s));
+    if (h_ctr.overflow) return set_error(kErrInternal, "SA build: bucket list overflow at depth %u", depth - kDigitBases);
+    nsegs = h_ctr.nnext;
+    nleaves_host = h_ctr.nleaves;
+    exact = true;
   }
+  if (!exact) return set_error(kErrInternal, "SA build: level count not read back");
   g_stats.v[0] = levels;
   g_stats.v[1] = nleaves_host;
   g_stats.v[4] = depth;
@@ -1442,6 +1518,24 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                ghead, depth, n, ctr);
   }
   BWT_CHECK_LAUNCH();
+  if (extras && extras->readback && !range && !nsegs) {
+    // the usual case has no tied rows: let the caller get on with it (see SaExtras)
+    static_assert(sizeof(Counters) <= 16 * sizeof(uint32_t), "readback words");
+    BWT_HIP(hipMemcpyAsync(extras->readback, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+    extras->bw = bw;
+    extras->endloc = &ctr->endloc;
+    extras->samples_done = samples != nullptr;
+    extras->pending = true;
+    extras->later.d_sa = d_sa;
+    extras->later.ghead = ghead;
+    extras->later.flags = bufB;  // free from here on
+    extras->later.leaves = leaves;
+    extras->later.leaf_ties = leaf_ties;
+    extras->later.ctr = ctr;
+    extras->later.n = n;
+    extras->later.nleaves = nleaves_host;
+    return kOk;
+  }
   BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
   BWT_HIP(hipStreamSynchronize(s));
   g_stats.v[2] = h_ctr.unresolved;
@@ -1467,6 +1561,26 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     BWT_TRY(sa_doubling(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
   }
   return kOk;
+}
+
+int sa_build_settle(SaExtras *extras, hipStream_t s) {
+  if (!extras || !extras->pending) return 0;
+  extras->pending = false;
+  Counters h_ctr;
+  std::memcpy(&h_ctr, extras->readback, sizeof h_ctr);
+  g_stats.v[2] = h_ctr.unresolved;
+  if (!h_ctr.unresolved) return 0;
+  extras->bw = nullptr;
+  extras->endloc = nullptr;
+  extras->samples_done = false;
+  if (extras->later.nleaves)
+    BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(extras->later.nleaves), dim3(256), 0, s,
+               static_cast<const Leaf *>(extras->later.leaves), static_cast<const uint8_t *>(extras->later.leaf_ties),
+               extras->later.ghead);
+  BWT_TRY(sa_doubling(extras->later.d_sa, extras->later.ghead, extras->later.n, h_ctr.min_depth,
+                      extras->later.flags, static_cast<Counters *>(extras->later.ctr), s));
+  BWT_HIP(hipStreamSynchronize(s));
+  return 1;
 }
 
 }  // namespace bwtgpu
