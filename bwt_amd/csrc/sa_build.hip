@@ -889,12 +889,15 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
             uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
             uint8_t *__restrict__ leaf_ties /* per leaf: 1 if it wrote tie-group heads */,
             uint32_t *__restrict__ samples /* SA[8 i] at samples[i], or null */,
-            Counters *__restrict__ ctr) {
+            Counters *__restrict__ ctr, uint32_t first_leaf) {
+  // the grid may be sized by a guess made before the host knew the number of leaves
+  const uint32_t leaf = first_leaf + blockIdx.x;
+  if (leaf >= ctr->nleaves) return;
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
   __shared__ uint32_t wred[kLeafWaves], wmax[kLeafWaves];
   __shared__ uint32_t bcnt[kLeafBuckets / 2], bred[2 * kLeafWaves];
-  const Leaf lf = leaves[blockIdx.x];
+  const Leaf lf = leaves[leaf];
   const uint32_t t = threadIdx.x, size = lf.size, start = lf.start, depth = lf.depth;
   const uint32_t srcid = lf.src & 255u, keybases = lf.src >> 8;
   const uint32_t *src = srcid == kSrcA ? bufA : srcid == kSrcB ? bufB : nullptr;
@@ -905,7 +908,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
       const uint32_t id = word_id(w);
       sa_rows[start] = id;
       if (samples && !((1 + start) & kDevSampleMask)) samples[(1 + start) >> kDevSampleShift] = id;
-      leaf_ties[blockIdx.x] = 0;
+      leaf_ties[leaf] = 0;
       bw[start] = (uint8_t)(w & 3u);
       if (id == 0) ctr->endloc = 1 + start;
     }
@@ -1083,7 +1086,7 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     if (k < per && j < size) keys[pad(j)] = outv[k];
   }
   __syncthreads();
-  if (t == 0) leaf_ties[blockIdx.x] = ties ? 1 : 0;
+  if (t == 0) leaf_ties[leaf] = ties ? 1 : 0;
   for (uint32_t j = t; j < size; j += kLeafThreads) {
     const uint64_t o = keys[pad(j)];
     sa_rows[start + j] = (uint32_t)o;
@@ -1398,6 +1401,8 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   if (n <= kLeafMax) {
     const Leaf whole = {0, n, 0, leaf_src_word(kSrcImplicit, kLeafKeyBases)};
     BWT_HIP(hipMemcpyAsync(leaves, &whole, sizeof whole, hipMemcpyHostToDevice, s));
+    const uint32_t one = 1;
+    BWT_HIP(hipMemcpyAsync(&ctr->nleaves, &one, 4, hipMemcpyHostToDevice, s));
     nleaves_host = 1;
   } else {
     const Seg whole = {0, n};
@@ -1415,6 +1420,17 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   int expected_levels = 1;
   for (uint64_t per = (uint64_t)n >> 8; per > kLeafMax; per >>= 8) ++expected_levels;
   bool exact = true;  // nsegs is the count the device holds, not a bound on it
+  uint32_t leaves_sorted = 0;  // leaves [0, leaves_sorted) have been handed to the leaf sort already
+  struct EventHolder {
+    hipEvent_t ev = nullptr;
+    ~EventHolder() {
+      if (ev) (void)hipEventDestroy(ev);
+    }
+  } ahead;
+  if (extras && extras->readback && hipEventCreateWithFlags(&ahead.ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    ahead.ev = nullptr;
+  }
   int levels = 0;
   uint32_t reach = 0;  // the words stored with the ids hold the text up to this base (exclusive)
   while (nsegs > 0 && depth < kMaxDepth) {
@@ -1498,8 +1514,22 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       exact = false;
       continue;
     }
-    BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
-    BWT_HIP(hipStreamSynchronize(s));
+    if (extras && extras->readback && ahead.ev && levels == expected_levels) {
+      // The counters go to pinned memory and the host waits for that copy alone,
+      // while the device already sorts the leaves there are so far -- about as
+      // many as this guess, the rest (if any) after the last level.
+      BWT_HIP(hipMemcpyAsync(extras->readback, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+      BWT_HIP(hipEventRecord(ahead.ev, s));
+      const uint32_t guess = n / (kLeafMax * 3 / 4) + 1;
+      BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(guess), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
+                 leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, 0u);
+      BWT_HIP(hipEventSynchronize(ahead.ev));
+      std::memcpy(&h_ctr, extras->readback, sizeof h_ctr);
+      leaves_sorted = h_ctr.nleaves < guess ? h_ctr.nleaves : guess;
+    } else {
+      BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+      BWT_HIP(hipStreamSynchronize(s));
+    }
     if (h_ctr.overflow) return set_error(kErrInternal, "SA build: bucket list overflow at depth %u", depth - kDigitBases);
     nsegs = h_ctr.nnext;
     nleaves_host = h_ctr.nleaves;
@@ -1509,9 +1539,9 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   g_stats.v[0] = levels;
   g_stats.v[1] = nleaves_host;
   g_stats.v[4] = depth;
-  if (nleaves_host)
-    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
-               leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr);
+  if (nleaves_host > leaves_sorted)
+    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host - leaves_sorted), dim3(kLeafThreads), 0, s, tb, bufA,
+               bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, leaves_sorted);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
     BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
