@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rate of the align_read_anchored kernel on the GPU box, and of the reference's function on one core."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth
 from oracle import load_oracle, load_reference

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Large-genome run on the GPU box: build, search, locate, self-checks."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth
 G.init(0)

@@ -8,7 +8,7 @@
                                                  the number of builds (warm-up build included in it)
 """
 import csv, glob, json, os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 if sys.argv[1] == "run":
     import torch

@@ -18,6 +18,6 @@ echo "pmc fetch rc=$?"
 timeout -s KILL 280 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --config c4 --steps 3 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 echo "pmc write rc=$?"
 cd $GRAFT_REPO_ROOT
-python3 tools_pmc_summary.py $OUT k_search k_locate_sa k_leaf_sort k_part_scatter k_part_hist k_isa_deal k_isa_fill k_kmer_level 2>&1 | tail -30
+python3 tools/tools_pmc_summary.py $OUT k_search k_locate_sa k_leaf_sort k_part_scatter k_part_hist k_isa_deal k_isa_fill k_kmer_level 2>&1 | tail -30
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/c4_kernel_stats.csv
 find $OUT -name "*.db" -delete; find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Cost of the reference-API calls (host buffers in, host structs out) on the GPU box."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bwt_amd import _lib, synth
 hl = C.CDLL(_lib.LIB_PATH)

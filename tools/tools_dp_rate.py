@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Rate of the nw_fast / sw_fast batch kernel on the GPU box, and of the reference's own functions on one core."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from bwt_amd import gpu as G
 from oracle import load_oracle, load_reference

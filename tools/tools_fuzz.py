@@ -3,8 +3,8 @@
 kinds, every product of the build and every search form against the CPU oracle.
 usage: tools_fuzz.py <seconds> [first_seed] [max_n]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth, dist as D, _lib
 from oracle import load_oracle

@@ -3,7 +3,7 @@
 bytes in pageable memory (packed by host threads on the way), packed words in pageable
 memory, packed words in pinned memory."""
 import ctypes as C, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth, _lib
 G.init(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scalar calls through the reference's C API on the GPU box: one thread, then four at once (fmitest.c:67-91)."""
 import ctypes as C, os, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bwt_amd import _lib
 from oracle import load_oracle

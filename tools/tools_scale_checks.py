@@ -3,7 +3,7 @@
 path) and the 250 Mbp genome built in 8 shards, each suffix array certified on
 the host (permutation + order, O(n))."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth, dist as D
 from oracle import load_oracle, load_reference

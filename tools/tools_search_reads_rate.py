@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rate of the search_reads anchor-loop kernel and of mms on the GPU box."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bwt_amd import gpu as G, synth, _lib
 G.init(0)

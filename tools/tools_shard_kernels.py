@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel times of ONE shard of an 8-rank build (what a rank does before the exchange)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bwt_amd import gpu as G, synth, dist as D
 G.init(0)

@@ -5,7 +5,7 @@ sorts), of packing its symbols, of assembling the index from every shard's
 products, of attaching the gathered rows, and the bytes a rank receives in the
 two exchanges.  The one-GPU whole build is timed beside them."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from bwt_amd import gpu as G, synth, dist as D
 
