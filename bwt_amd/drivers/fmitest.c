@@ -5,6 +5,10 @@
  * from make_fmi; the 10,000,000 overlapping 12-mers that the reference hands
  * to four pthreads (fmitest.c:54-91) go to the device in one batch.
  * Times are wall clock; the "cycles" figure is the TSC delta, as there.
+ * A last line says how many of the 12-mers occur in the text; with a second
+ * argument the text and the patterns are written to that file (len/4+1 bytes,
+ * then 10,000,011), so that a test can count for itself: the rand() stream is
+ * not the same from process to process once a GPU runtime has been loaded.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,7 +24,7 @@ static double now(void) {
 }
 
 int main(int argc, char **argv) {
-  if (argc != 2) {
+  if (argc != 2 && argc != 3) {
     fprintf(stderr, "Usage: fmitest len\n");
     exit(-1);
   }
@@ -59,6 +63,14 @@ int main(int argc, char **argv) {
   long hits = 0;
   for (long i = 0; i < npat; ++i) hits += res[i] > 1;
   printf("(%ld of them occur in the text)\n", hits);
+  if (argc == 3) {
+    FILE *f = fopen(argv[2], "wb");
+    if (!f || fwrite(str, 1, len / 4 + 1, f) != (size_t)(len / 4 + 1) || fwrite(pats, 1, npat + 11, f) != (size_t)(npat + 11) ||
+        fclose(f)) {
+      fprintf(stderr, "Could not write %s\n", argv[2]);
+      return 1;
+    }
+  }
 
   destroy_fmi(fmi);
   free(str);

@@ -150,6 +150,21 @@ class GpuIndex:
                                                _stream()))
         return (sp, ep, lr) if want_locrow else (sp, ep)
 
+    def search_packed(self, d_words, m, R, want_locrow=False, out=None):
+        """bwtgpu_search_packed: reads already packed to 2 bits per base, read r the
+        (m+15)//16 int32 words at d_words[r * ((m+15)//16):] (pack_reads_dev's format)."""
+        wpr = (m + 15) // 16
+        if d_words.numel() < R * wpr:
+            raise ValueError(f"packed buffer holds {d_words.numel()} words, needs {R * wpr}")
+        if out is None:
+            sp = torch.empty(R, dtype=torch.int32, device="cuda")
+            ep = torch.empty(R, dtype=torch.int32, device="cuda")
+            lr = torch.empty(R, dtype=torch.int32, device="cuda") if want_locrow else None
+        else:
+            sp, ep, lr = out
+        check(_lib.load().bwtgpu_search_packed(self.h, _ptr(d_words), m, R, _ptr(sp), _ptr(ep), _ptr(lr), _stream()))
+        return (sp, ep, lr) if want_locrow else (sp, ep)
+
     def search_loads(self, d_pats, m, R, stride=None):
         """Loads one search of the batch makes: dict of counts (see
         bwtgpu_search_profile) and the bytes they add up to."""
@@ -287,6 +302,25 @@ def build_index_from_sa(d_text, n, d_sa, d_bw=None, endloc=0):
     assert d_sa.numel() >= n + 1 and (d_bw is None or d_bw.numel() >= n)
     return GpuIndex(_lib.load().bwtgpu_index_build_from_sa(_ptr(d_text), n, _ptr(d_sa), _ptr(d_bw), endloc,
                                                            _stream()))
+
+
+def pack_reads_dev(d_pats, m, R, chunk=1 << 20):
+    """R reads of m bases, one base per byte at d_pats[r * m:], packed on the device
+    with torch ops into the format of bwtgpu_search_packed: (m+15)//16 words per
+    read, base k at bits 2 (k % 16) of word k // 16.  Set-up code for benches and
+    tests (the product packs inside its search kernel, or on the host)."""
+    wpr = (m + 15) // 16
+    out = torch.empty(R * wpr, dtype=torch.int32, device="cuda")
+    shifts = (2 * torch.arange(16, device="cuda", dtype=torch.int64)).view(1, 1, 16)
+    for r0 in range(0, R, chunk):
+        r1 = min(R, r0 + chunk)
+        b = d_pats[r0 * m:r1 * m].view(r1 - r0, m).to(torch.int64) & 3
+        if wpr * 16 != m:
+            b = torch.nn.functional.pad(b, (0, wpr * 16 - m))
+        w = (b.view(r1 - r0, wpr, 16) << shifts).sum(dim=2)
+        w = torch.where(w >= (1 << 31), w - (1 << 32), w).to(torch.int32)
+        out[r0 * wpr:r1 * wpr] = w.reshape(-1)
+    return out
 
 
 def pack_bw2(d_bw, rows):

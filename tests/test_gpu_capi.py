@@ -239,12 +239,39 @@ def test_build_index_driver_writes_the_reference_file(oracle, tmp_path):
     assert idx.read_bytes() == want
 
 
-def test_fmitest_driver_runs(tmp_path):
+def test_fmitest_driver_counts_what_the_text_holds(tmp_path):
+    """drivers/fmitest draws its text and its 10^7 overlapping 12-mers from
+    rand(), as fmitest.c:127-153 does; the number of 12-mers it reports as found
+    must be the number that occur in that text (counted here with numpy from the
+    inputs the driver writes out when given a second argument)."""
+    import re
+    import numpy as np
+
+    n, npat, m = 1000000, 10000000, 12
     exe = os.path.join(ROOT, "bwt_amd", "drivers", "fmitest")
-    out = subprocess.run([exe, "1000000"], capture_output=True, text=True, timeout=300)
+    dump = tmp_path / "inputs.bin"
+    out = subprocess.run([exe, str(n), str(dump)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert "Built index with 1000000 base pairs" in out.stdout
     assert "Searched 10000000 12bp sequences" in out.stdout
+    got = int(re.search(r"\((\d+) of them occur in the text\)", out.stdout).group(1))
+
+    raw = np.fromfile(dump, dtype=np.uint8)
+    packed, pats = raw[: n // 4 + 1], raw[n // 4 + 1:]
+    assert pats.size == npat + 11
+    bases = ((packed[:, None] >> np.array([6, 4, 2, 0], dtype=np.uint8)) & 3).reshape(-1)[:n].astype(np.uint32)
+
+    def codes(b, count):  # the m-mer starting at each of the first `count` positions, as a number
+        acc = np.zeros(count, dtype=np.uint32)
+        for k in range(m):
+            acc = (acc << 2) | b[k:k + count]
+        return acc
+
+    in_text = np.zeros(1 << (2 * m), dtype=bool)
+    in_text[codes(bases, n - m + 1)] = True
+    want = int(in_text[codes(pats.astype(np.uint32), npat)].sum())
+    assert 500000 < want < 650000  # about npat * n / 4^12
+    assert got == want
 
 
 def test_single_queries_on_the_host_and_on_the_device_agree(capi, oracle, monkeypatch):

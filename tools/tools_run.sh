@@ -11,6 +11,6 @@ print("search reads/s %.4g  ms/step %.3f  frac %.3f" % (d["value"], d["ms_per_st
 print("build Mbp/s %.5g wall_ms %.3f stats %s" % (d["sa_build"]["value"], d["sa_build"]["wall_ms"], d["sa_build"]["stats"]))
 print("build kernels", {k:v for k,v in d["sa_build"]["kernels_ms"].items() if v>0.02})
 print("search arrays", d["sa_build"]["search_arrays"]["wall_ms"], {k:v for k,v in d["sa_build"]["search_arrays"]["kernels_ms"].items() if v>0.02})
-print("locate", d["locate"]); print("bytes/read", d["roofline"]["bytes_per_read"], d["roofline"]["loads"], d["roofline"]["counting_pass_matches"]); print("rank_only", d["rank_only"])
+print("packed", d.get("packed_input")); print("locate", d["locate"]); print("bytes/read", d["roofline"]["bytes_per_read"], d["roofline"]["loads"], d["roofline"]["counting_pass_matches"]); print("rank_only", d["rank_only"])
 if "cpu_baseline" in d: print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["build_mbp_s"], d["cpu_baseline"]["gpu_matches_cpu"])
 PY
