@@ -674,8 +674,8 @@ def main():
             "counting_pass_matches": counted_ok,
             "kernel_ms": k_ms,
             "what": "bytes the kernel loads and stores, counted per batch by its counting build "
-                    "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries, 8 or 12 B table entry, the read itself, "
-                    "12 B out)",
+                    "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries and further table starts, 8 B table entry, "
+                    "the read itself, 12 B out)",
             "reads_packed_in_kernel": fused,
         },
         "packed_input": packed_leg,

@@ -208,6 +208,11 @@ struct bwtgpu_index {
   // all strings of ceil(log4 n) bases that occur at all), which saves such a search the
   // suffix-array line.  Two words when the index keeps its suffix array.
   uint32_t kmer_w = 1;
+  // Two-word entries, when text positions leave bits of the second word free (n < 2^30):
+  // its top kmer_sizebits bits hold the number of rows of the interval, capped at
+  // 2^kmer_sizebits - 1 ("that many or more: see where the next string starts"), so that
+  // a lookup is the entry's own 8 bytes and never the next entry's line.  0: not stored.
+  uint32_t kmer_sizebits = 0;
   int device = 0;
   // What make_fmi (seqindex.c:161-189) produces is complete when a build or a
   // load returns.  The arrays that only speed searches up (position records,

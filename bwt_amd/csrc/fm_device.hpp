@@ -16,6 +16,7 @@ struct IndexView {
   const uint32_t *kmer;   // null unless the index has the k-mer interval table
   uint32_t kmer_k;
   uint32_t kmer_w;        // words per table entry: 1 (start) or 2 (start, SA[start])
+  uint32_t kmer_sizebits; // top bits of a two-word entry's second word that hold the interval's size, or 0
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
@@ -23,7 +24,7 @@ struct IndexView {
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->kmer_k, ix->kmer_w, ix->nsym, ix->n, ix->endloc};
+                   ix->d_kmer,   ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
@@ -49,8 +50,11 @@ __device__ __forceinline__ uint32_t occ_c(const IndexView &v, uint32_t c,
 // table; empty when the two are equal.  pos (when the table has two words per
 // entry, else 0xFFFFFFFF): SA[sp], the text position of the string's first
 // occurrence in row order -- its only one when the interval is a single row.
-__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp, uint32_t &pos) {
+// next_read: whether the start of the next string had to be read as well (4 more bytes).
+__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp, uint32_t &pos,
+                                                 bool &next_read) {
   uint32_t ep;
+  next_read = v.kmer_w == 2;
   if (v.kmer_w == 2) {
     // start and position of x, start of x + 1: three words of one 16-byte-or-less span
     const uint32_t *e = v.kmer + 2ull * x;
@@ -58,6 +62,14 @@ __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x
     __builtin_memcpy(&mine, e, sizeof mine);
     sp = (uint32_t)mine;
     pos = (uint32_t)(mine >> 32);
+    if (v.kmer_sizebits) {  // the entry says how many rows, unless they are many
+      const uint32_t posbits = 32u - v.kmer_sizebits, size = pos >> posbits;
+      pos &= (1u << posbits) - 1u;
+      if (size < (1u << v.kmer_sizebits) - 1u) {
+        next_read = false;
+        return sp + size;
+      }
+    }
     ep = e[2];
   } else {
     // one 8-byte load at a 4-byte aligned address: both starts in one request
@@ -77,6 +89,10 @@ __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x
     ep -= (uint64_t)e.x == (uint64_t)x + 1 ? e.y : 0u;  // x + 1 does not fit 32 bits for the last string of 16 bases
   }
   return ep;
+}
+__device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp, uint32_t &pos) {
+  bool next_read;
+  return kmer_interval(v, x, sp, pos, next_read);
 }
 __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x, uint32_t &sp) {
   uint32_t pos;

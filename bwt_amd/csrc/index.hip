@@ -339,7 +339,8 @@ __device__ __forceinline__ void kmer_extend(const IndexView &v, uint2 iv, uint2 
 
 template <bool LAST>
 __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
-                             uint32_t *__restrict__ dst_start, uint32_t j, const uint32_t *__restrict__ sa) {
+                             uint32_t *__restrict__ dst_start, uint32_t j, const uint32_t *__restrict__ sa,
+                             uint32_t sizebits) {
   // one thread per string x of j bases: the two blocks its interval ends fall
   // in serve all four extensions c.x
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,8 +354,14 @@ __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *
     kmer_extend(v, iv, o);
     uint2 *entries = reinterpret_cast<uint2 *>(dst_start);
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c)
-      entries[(uint64_t)c * parents + p] = make_uint2(o[c].x, (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u);
+    for (uint32_t c = 0; c < 4; ++c) {
+      uint32_t second = (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u;
+      if (sizebits) {  // the interval's size in the bits a text position leaves free (see bwtgpu_index)
+        const uint32_t cap = (1u << sizebits) - 1u, size = o[c].y > o[c].x ? o[c].y - o[c].x : 0u;
+        second |= (size < cap ? size : cap) << (32u - sizebits);
+      }
+      entries[(uint64_t)c * parents + p] = make_uint2(o[c].x, second);
+    }
     return;
   }
   if (LAST) {
@@ -485,6 +492,10 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
     tmp_a = tmp_b = nullptr;
     if (K <= 6 || getenv("BWT_MI355X_KMER")) return kOk;
   }
+  // bits of an entry's second word that text positions (0..n) leave free take the interval's size
+  uint32_t posbits = 1;
+  while (posbits < 32 && (ix->n >> posbits)) ++posbits;
+  const uint32_t sizebits = (W == 2 && 32 - posbits >= 2) ? (32 - posbits < 6 ? 32 - posbits : 6u) : 0u;
   // level j < K lives in tmp_a when K - 1 - j is even, in tmp_b otherwise
   auto buf = [&](uint32_t j) { return ((K - 1 - j) & 1u) ? tmp_b : tmp_a; };
   const IndexView v = view_of(ix);
@@ -497,10 +508,11 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
     const uint64_t parents = 1ull << (2 * j);
     if (j + 1 < K)
       BWT_LAUNCH("kmer_level", k_kmer_level<false>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
-                 buf(j), buf(j + 1), (uint32_t *)nullptr, j, (const uint32_t *)nullptr);
+                 buf(j), buf(j + 1), (uint32_t *)nullptr, j, (const uint32_t *)nullptr, 0u);
     else
       BWT_LAUNCH("kmer_level", k_kmer_level<true>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
-                 buf(j), (uint2 *)nullptr, tab, j, W == 2 ? (const uint32_t *)ix->d_sa : (const uint32_t *)nullptr);
+                 buf(j), (uint2 *)nullptr, tab, j, W == 2 ? (const uint32_t *)ix->d_sa : (const uint32_t *)nullptr,
+                 sizebits);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -514,6 +526,7 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   ix->d_kmer = tab;
   ix->kmer_k = K;
   ix->kmer_w = W;
+  ix->kmer_sizebits = sizebits;
   return kOk;
 }
 

@@ -151,8 +151,12 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     x = __brev(x);
     x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);  // base a in the top bits
     uint32_t e_sp, e_pos;
-    const uint32_t e_ep = kmer_interval(v, x >> (32 - 2 * K), e_sp, e_pos);
-    if (COUNT) ++n_kmr;
+    bool e_next;
+    const uint32_t e_ep = kmer_interval(v, x >> (32 - 2 * K), e_sp, e_pos, e_next);
+    if (COUNT) {
+      ++n_kmr;  // 8 bytes: two starts, or a start and the position word
+      n_ent += e_next ? 1u : 0u;
+    }
     if (e_ep > e_sp) {
       sp = e_sp;
       ep = e_ep;

@@ -178,7 +178,7 @@ class GpuIndex:
                                         ws.numel(), loads, _stream()))
         blk, txt, ent, pat, kmr = (int(x) for x in loads)
         k, w = self.kmer_table
-        per_entry = 12 if w == 2 else 8  # two neighbouring starts, and the position between them in a two-word table
+        per_entry = 8  # two neighbouring starts, or a start and its position word; a further start read is among `ent`
         return {"rank_blocks_16B": blk, "text_windows_16B": txt, "sa_isa_entries_4B": ent,
                 "pattern_words_4B": pat, "kmer_entries": kmr, "kmer_entry_bytes": per_entry, "kmer_k": k,
                 "bytes": 16 * blk + 16 * txt + 4 * ent + 4 * pat + per_entry * kmr}, sp, ep

@@ -250,7 +250,8 @@ int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
                          uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
                          uint32_t *d_locrow, void *stream);
 /* bwtgpu_search, and the number of loads the batch made: loads[0] 16-byte rank
- * blocks, loads[1] 16-byte text windows, loads[2] 4-byte SA/ISA entries,
+ * blocks, loads[1] 16-byte text windows, loads[2] 4-byte SA/ISA entries (and
+ * 4-byte starts of the next string where a table lookup needed one),
  * loads[3] 4-byte packed pattern words, loads[4] 8-byte k-mer table lookups.
  * For measurement (bytes a search
  * needs); slower than bwtgpu_search and synchronises the stream.  Workspace:
