@@ -384,6 +384,36 @@ __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *
   for (uint32_t c = 0; c < 4; ++c) dst[(uint64_t)c * parents + p] = o[c];
 }
 
+// The last two levels of a two-word table in one pass: a thread takes a string g
+// of K - 2 bases, extends it to its four children and each child to its four, and
+// writes the sixteen finished entries; the level in between never goes to memory
+// (it is half as large again as everything below it).
+__global__ void __launch_bounds__(256)
+k_kmer_last_two(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ entries, uint32_t j /* = K - 2 */,
+                const uint32_t *__restrict__ sa, uint32_t sizebits) {
+  const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t grand = 1ull << (2 * j);
+  if (g >= grand) return;
+  uint2 mid[4];
+  kmer_extend(v, src[g], mid);
+  const uint32_t cap = sizebits ? (1u << sizebits) - 1u : 0u;
+#pragma unroll
+  for (uint32_t c1 = 0; c1 < 4; ++c1) {
+    uint2 o[4];
+    kmer_extend(v, mid[c1], o);
+    const uint64_t p = (uint64_t)c1 * grand + g;  // the child's number among the strings of K - 1 bases
+#pragma unroll
+    for (uint32_t c = 0; c < 4; ++c) {
+      uint32_t second = (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u;
+      if (sizebits) {
+        const uint32_t size = o[c].y > o[c].x ? o[c].y - o[c].x : 0u;
+        second |= (size < cap ? size : cap) << (32u - sizebits);
+      }
+      entries[(uint64_t)c * 4 * grand + p] = make_uint2(o[c].x, second);
+    }
+  }
+}
+
 struct KmerFirst {
   uint32_t c[5];
 };
@@ -481,7 +511,9 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   for (;; --K) {
     entries = 1ull << (2 * K);
     const size_t tab_bytes = (entries * W + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2);
-    if (pool_alloc(&tab, tab_bytes) == hipSuccess && pool_alloc(&tmp_a, (entries / 4) * sizeof(uint2)) == hipSuccess &&
+    // tmp_a holds levels K - 1, K - 3, ..; a two-word table of 7 bases or more never stores level K - 1 (k_kmer_last_two)
+    const uint64_t a_entries = (W == 2 && K >= 7) ? entries / 64 : entries / 4;
+    if (pool_alloc(&tab, tab_bytes) == hipSuccess && pool_alloc(&tmp_a, a_entries * sizeof(uint2)) == hipSuccess &&
         pool_alloc(&tmp_b, (entries / 16) * sizeof(uint2)) == hipSuccess)
       break;
     (void)hipGetLastError();  // short of memory: a smaller table, or none (searches then start from the first base)
@@ -506,6 +538,12 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   hipError_t e = hipGetLastError();
   for (uint32_t j = top; j < K && e == hipSuccess; ++j) {
     const uint64_t parents = 1ull << (2 * j);
+    if (W == 2 && j + 2 == K) {
+      BWT_LAUNCH("kmer_level", k_kmer_last_two, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v, buf(j),
+                 reinterpret_cast<uint2 *>(tab), j, (const uint32_t *)ix->d_sa, sizebits);
+      e = hipGetLastError();
+      break;
+    }
     if (j + 1 < K)
       BWT_LAUNCH("kmer_level", k_kmer_level<false>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
                  buf(j), buf(j + 1), (uint32_t *)nullptr, j, (const uint32_t *)nullptr, 0u);
