@@ -87,6 +87,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
   uint32_t c = pat[(len - 1) * step] & 3u;
   uint32_t start = c_of(C, c), end = c_of(C, c + 1);
   int i = len - 2;
+  uint32_t table_pos = 0xFFFFFFFFu;  // SA[start] when the table gave a single row and said where it lies
   const int K = (int)v.kmer_k;
   if (K && len >= K) {
     uint32_t x = hx;
@@ -101,12 +102,13 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
       }
     }
     if (plain) {
-      uint32_t e_sp;
-      const uint32_t e_ep = kmer_interval(v, x, e_sp);
+      uint32_t e_sp, e_pos;
+      const uint32_t e_ep = kmer_interval(v, x, e_sp, e_pos);
       if (e_ep > e_sp) {
         start = e_sp;
         end = e_ep;
         i = len - K - 1;
+        if (e_ep - e_sp == 1) table_pos = e_pos;  // consumed by the first pass of the loop below, before any step
       } else if (K <= at_least && skips == 0) {
         // fewer than K bases match and none was skipped: below the caller's bar
         *sp_out = 0;
@@ -121,7 +123,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     sp = start;
     ep = end;
     if (v.isa && end - start == 1) {
-      const uint32_t pos = v.sa[start];
+      const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : v.sa[start];
       uint32_t k = 0;  // bases that agree with the text in front of pos
       if (WAVE) {
         const uint32_t lane = threadIdx.x & 63u;
@@ -172,6 +174,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
       start = occ_sym(v, c, start);
       end = occ_sym(v, c, end);
     }
+    table_pos = 0xFFFFFFFFu;  // the interval has moved on from the table's
   }
   if (end <= start) {
     *sp_out = sp;
