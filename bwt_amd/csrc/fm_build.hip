@@ -305,9 +305,16 @@ __global__ void k_make_text2(const uint8_t *__restrict__ text, uint32_t n, uint6
   if (w >= 1) {
     const uint64_t first = 16 * (w - 1);
     const uint64_t nbytes = (uint64_t)n / 4 + 1;
-    for (uint32_t k = 0; k < 16; ++k) {
-      const uint64_t p = first + k;
-      if (p < n && (p >> 2) < nbytes) out |= text_base(text, p) << (2 * k);
+    if (first + 16 <= n && !((uintptr_t)text & 3u)) {
+      // four whole bytes: one load, then the four bases of every byte change places
+      uint32_t v = reinterpret_cast<const uint32_t *>(text)[w - 1];
+      v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+      out = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    } else {
+      for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t p = first + k;
+        if (p < n && (p >> 2) < nbytes) out |= text_base(text, p) << (2 * k);
+      }
     }
   }
   text2[w] = out;
