@@ -72,6 +72,7 @@ SIGNATURES = {
     "bwtgpu_index_build_from_shards": (vp, [vp, u32, u32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64),
                                             vp, vp, vp]),
     "bwtgpu_index_attach_sa": (C.c_int, [vp, vp, vp, vp]),
+    "bwtgpu_index_keep_lean": (C.c_int, [vp]),
     "bwtgpu_index_build_from_sa": (vp, [vp, u32, vp, vp, u32, vp]),
     "bwtgpu_search_profile": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, sz, vp, vp]),
     "bwtgpu_index_compact": (C.c_int, [vp]),

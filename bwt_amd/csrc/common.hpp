@@ -221,6 +221,9 @@ struct bwtgpu_index {
   // file never pays for them.  want_*: the array can be and is to be made.
   bool want_records = false;  // d_sa and d_text2 are in place
   bool want_kmer = false;
+  // A loaded index (BWT + sampled rows): recompute the suffix array and the text
+  // from them first, so that it gets the same search-only arrays as a built one.
+  bool want_recover = false;
   mutable std::atomic<bool> search_ready{true};  // nothing left for index_prepare_search to do
   mutable std::mutex prepare_mu;
 };
@@ -257,6 +260,8 @@ inline int index_ready_for_search(const bwtgpu_index *ix, hipStream_t s) {
 void index_defer_search_arrays(bwtgpu_index *ix);
 // fm_build.hip: the position records of an index that holds d_sa and d_text2
 int index_build_records(bwtgpu_index *ix, hipStream_t s);
+// search.hip: d_sa and d_text2 of an index that was loaded from its parts
+int index_recover_arrays(bwtgpu_index *ix, hipStream_t s);
 int index_alloc(bwtgpu_index **out, uint32_t n);
 
 // sa_build.hip

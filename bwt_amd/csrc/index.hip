@@ -573,7 +573,7 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
 void index_defer_search_arrays(bwtgpu_index *ix) {
   ix->want_records = ix->d_sa && ix->d_text2 && !ix->d_isa;
   ix->want_kmer = !ix->d_kmer && kmer_table_k(ix->n, ix->d_sa != nullptr) != 0;
-  ix->search_ready.store(!(ix->want_records || ix->want_kmer), std::memory_order_release);
+  ix->search_ready.store(!(ix->want_records || ix->want_kmer || ix->want_recover), std::memory_order_release);
 }
 
 int index_prepare_search(const bwtgpu_index *cix, hipStream_t s) {
@@ -584,11 +584,18 @@ int index_prepare_search(const bwtgpu_index *cix, hipStream_t s) {
   BWT_HIP(hipGetDevice(&cur));
   if (cur != ix->device) BWT_HIP(hipSetDevice(ix->device));
   int rc = kOk;
-  if (ix->want_records) rc = index_build_records(ix, s);
+  if (ix->want_recover) {
+    rc = index_recover_arrays(ix, s);
+    if (rc == kOk && ix->d_sa) {
+      ix->want_records = !ix->d_isa;
+      ix->want_kmer = !ix->d_kmer && kmer_table_k(ix->n, true) != 0;
+    }
+  }
+  if (rc == kOk && ix->want_records) rc = index_build_records(ix, s);
   if (rc == kOk && ix->want_kmer) rc = index_build_kmer_table(ix, s);  // synchronises the stream
   if (cur != ix->device) (void)hipSetDevice(cur);
   if (rc != kOk) return rc;
-  ix->want_records = ix->want_kmer = false;
+  ix->want_records = ix->want_kmer = ix->want_recover = false;
   ix->search_ready.store(true, std::memory_order_release);
   return kOk;
 }
@@ -707,8 +714,11 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
                        reinterpret_cast<const uint4 *>(d_bwt), ix->d_blocks, nb, n);
   }
   int rc = index_finish_from_planes(ix, s);
-  if (rc == kOk) index_defer_search_arrays(ix);  // the k-mer table waits for the first search
   ix->has_samples = h_idxs != nullptr;
+  // the first search recomputes the suffix array and the text from BWT and samples,
+  // then makes the search-only arrays a built index has (index_recover_arrays)
+  ix->want_recover = h_idxs != nullptr && !getenv("BWT_MI355X_COMPACT") && n <= kPosRecordMaxN;
+  if (rc == kOk) index_defer_search_arrays(ix);  // ... and the k-mer table
   uint32_t broken = 0;
   if (rc == kOk && h_idxs) {
     // the first word of the (no longer needed) BWT staging buffer takes the "walk did not end" flag
@@ -775,8 +785,18 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
   ix->kmer_k = 0;
-  ix->want_records = ix->want_kmer = false;
+  ix->want_records = ix->want_kmer = ix->want_recover = false;
   ix->search_ready.store(true, std::memory_order_release);
+  return kOk;
+}
+
+int bwtgpu_index_keep_lean(bwtgpu_index *ix) {
+  if (!ix) return set_error(kErrArg, "null index");
+  std::lock_guard<std::mutex> lock(ix->prepare_mu);
+  if (ix->want_recover) {
+    ix->want_recover = false;
+    ix->search_ready.store(!(ix->want_records || ix->want_kmer), std::memory_order_release);
+  }
   return kOk;
 }
 

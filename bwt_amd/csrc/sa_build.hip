@@ -441,11 +441,13 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
     if (lane == 63) wsum[wave] = v;
   }
   __syncthreads();
+  // the claim of global room is in flight while the tile is put in bucket order
+  uint32_t claimed = 0;
   if (t < 256) {
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
     lstart[t] = pre + v - c;
-    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+    if (c) claimed = atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c);
   }
   __syncthreads();
 #pragma unroll
@@ -457,6 +459,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
       kv[p] = key[i];
     }
   }
+  if (t < 256) gbase[t] = claimed;
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
   for (uint32_t j = t; j < placed; j += kScatThreads) {
@@ -595,7 +598,7 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
   }
   __syncthreads();
   const uint32_t lane = t & 63u, wave = t >> 6;
-  uint32_t c = 0, v = 0;
+  uint32_t c = 0, v = 0, claimed = 0;
   if (t < 256) {
     c = hist[t];
     v = c;
@@ -610,7 +613,7 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
     uint32_t pre = 0;
     for (uint32_t q = 0; q < wave; ++q) pre += wsum[q];
     lstart[t] = pre + v - c;
-    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)(blockIdx.x & 7u) * 256 + t], c) : 0u;
+    if (c) claimed = atomicAdd(&cursors[(uint64_t)(blockIdx.x & 7u) * 256 + t], c);
   }
   __syncthreads();
 #pragma unroll
@@ -626,6 +629,7 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
       kv[p] = (key & ~3u) | ((row0 + p0 + q) ? bw : 0u);
     }
   }
+  if (t < 256) gbase[t] = claimed;  // the claim was in flight while the tile was put in order
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
   for (uint32_t j = t; j < placed; j += kScatThreads) {

@@ -360,7 +360,7 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
         if (!active[s]) {
           const uint64_t cand = first + (uint64_t)__popcll(need[s] & low_mask(lane));
           if (cand < loc_hi) {
-            const uint32_t row = rows[cand];
+            const uint32_t row = rows ? rows[cand] : (uint32_t)cand;  // no list: every row in turn
             if (row > v.n) {
               pos[cand] = 0xFFFFFFFFu;
             } else {
@@ -412,6 +412,68 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
     for (int off = 32; off; off >>= 1) my_steps += __shfl_down(my_steps, off, 64);
     if (lane == 0 && my_steps) atomicAdd(steps_total, my_steps);
   }
+}
+
+// The text from the suffix array and the BWT: the symbol of row r is the base
+// in front of suffix SA[r] (histsortcomp.c:227-239 read backwards).  text2 is
+// zeroed beforehand; sixteen rows, anywhere in the suffix array, share a word.
+__global__ void k_text_from_bwt(IndexView v, const uint32_t *__restrict__ sa, uint32_t *__restrict__ text2) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > v.n) return;
+  const uint32_t p = sa[r];
+  if (p == 0 || p > v.n) return;  // the $ row: nothing precedes suffix 0
+  const uint32_t j = (uint32_t)r - ((uint32_t)r > v.endloc);
+  const IndexBlock *b = v.blocks + (j >> 6);
+  const uint32_t c = (uint32_t)((b->lo >> (j & 63u)) & 1ull) | ((uint32_t)((b->hi >> (j & 63u)) & 1ull) << 1);
+  const uint32_t q = p - 1;
+  if (c) atomicOr(&text2[1 + (q >> 4)], c << (2u * (q & 15u)));
+}
+
+// An index loaded from its parts (BWT, sampled rows) has everything from which
+// the arrays a built index keeps can be recomputed: every row of the suffix
+// array by the walk unc_sa does (seqindex.c:244-255), then the text from rows
+// and BWT.  With them the loaded index gets position records and a two-word
+// k-mer table like a built one.  Not an error when HBM is short: the index then
+// searches on its rank blocks.  Waits for `s`.
+int index_recover_arrays(bwtgpu_index *ix, hipStream_t s) {
+  if (ix->d_sa || !ix->has_samples) return kOk;
+  const uint32_t n = ix->n;
+  const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  unsigned long long *head = nullptr;
+  hipError_t e = pool_alloc(&ix->d_sa, rows * 4);
+  if (e == hipSuccess) e = pool_alloc(&ix->d_text2, t2words * 4);
+  if (e == hipSuccess) e = pool_alloc(&head, 256);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    pool_free(ix->d_sa);
+    pool_free(ix->d_text2);
+    pool_free(head);
+    ix->d_sa = ix->d_text2 = nullptr;
+    return kOk;
+  }
+  IndexView v = view_of(ix);
+  v.sa = nullptr;  // the walks must not read what they are writing
+  e = hipMemsetAsync(head, 0, 256, s);
+  if (e == hipSuccess) e = hipMemsetAsync(ix->d_text2, 0, t2words * 4, s);
+  if (e == hipSuccess) {
+    uint64_t groups = div_up(div_up(rows, (uint64_t)kLocateBatch), 4);
+    if (groups > 256 * 8) groups = 256 * 8;
+    BWT_LAUNCH("recover_sa", k_locate, dim3((unsigned)groups), dim3(256), 0, s, v, (const uint32_t *)nullptr, rows,
+               ix->d_sa, (unsigned long long *)nullptr, head);
+    BWT_LAUNCH("recover_text", k_text_from_bwt, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, v,
+               (const uint32_t *)ix->d_sa, ix->d_text2);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  pool_free(head);
+  if (e != hipSuccess) {
+    (void)hipDeviceSynchronize();
+    pool_free(ix->d_sa);
+    pool_free(ix->d_text2);
+    ix->d_sa = ix->d_text2 = nullptr;
+    return set_error(kErrHip, "recovering the suffix array of a loaded index: %s", hipGetErrorString(e));
+  }
+  return kOk;
 }
 
 // Scratch of bwtgpu_search_static: the packed reads of a batch whose reads are

@@ -233,15 +233,21 @@ class GpuIndex:
         return pos
 
 
-def index_from_parts(bwt, n, endloc, idxs):
+def index_from_parts(bwt, n, endloc, idxs, lean=False):
     """Stored parts of an index (numpy, host) -> HBM index; the device-side
-    counterpart of read_index's rebuild (fileio.c:62-63)."""
+    counterpart of read_index's rebuild (fileio.c:62-63).  lean: the index stays
+    on rank blocks, sampled rows and k-mer table (bwtgpu_index_keep_lean); else
+    its first search recomputes suffix array and text and it searches like a
+    built one."""
     bwt = np.ascontiguousarray(bwt, np.uint8)
     idxs = np.ascontiguousarray(idxs, np.uint32)
     assert len(bwt) >= (n + 3) // 4 and len(idxs) >= 1 + n // 32
     h = _lib.load().bwtgpu_index_from_parts(bwt.ctypes.data_as(C.c_void_p), n, endloc,
                                             idxs.ctypes.data_as(C.c_void_p), _stream())
-    return GpuIndex(h)
+    ix = GpuIndex(h)
+    if lean:
+        check(_lib.load().bwtgpu_index_keep_lean(ix.h))
+    return ix
 
 
 def build_index(text, n):

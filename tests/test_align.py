@@ -64,7 +64,7 @@ def test_gpu_align_equals_the_oracle_and_the_golden_vectors(oracle, gpu):
     fo = oracle.make_fmi(text, n)
     want = [oracle.align_read_anchored(fo, text, rd, rec["anchor"]) for rd in reads]
     full = gpu.build_index(text, n)
-    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     for name, ix in (("built from the text", full), ("loaded from parts", lean)):
         got = _gpu_align(gpu, ix, text, reads, rec["anchor"], 160)
         for rd, g, w in zip(reads, got, want):
@@ -134,7 +134,7 @@ def test_gpu_align_on_repeats(oracle, gpu, period, mutations):
     fo = oracle.make_fmi(text, n)
     reads = align_cases(synth.unpack(text, n), n, 300, 1234 + period, lo=30, hi=120)
     want = [oracle.align_read_anchored(fo, text, rd, 12) for rd in reads]
-    for ix in (gpu.build_index(text, n), gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)):
+    for ix in (gpu.build_index(text, n), gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)):
         got = _gpu_align(gpu, ix, text, reads, 12, 130)
         for rd, g, w in zip(reads, got, want):
             assert g == w, len(rd)

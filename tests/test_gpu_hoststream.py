@@ -45,7 +45,7 @@ def test_streamed_host_search_equals_device_search(oracle, gpu, m, R, built):
     n = 1_000_003
     text = oracle.gen_genome(n, synth.GENOME_SEED + m)
     fo = oracle.make_fmi(text, n)
-    ix = gpu.build_index(text, n) if built else gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.build_index(text, n) if built else gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     reads, _ = oracle.gen_reads(text, n, R, m, 77 + m)
     reads = np.ascontiguousarray(reads)
     d = torch.from_numpy(np.concatenate([reads.reshape(-1), np.zeros(64, np.uint8)])).cuda()

@@ -58,7 +58,7 @@ def test_mms_mismatching_reads_and_scalar_call(oracle, gpu):
             reads[r, m - k:] = bases[:k]
     want = [oracle.mms(fo, reads[r]) for r in range(R)]
     # index with SA/ISA/text and table, index from stored parts (table only), bare rank blocks
-    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     for name, index in (("full", ix), ("from parts", lean)):
         got, sp, ep = _mms(gpu, index, reads)
         assert [(int(a), int(b), int(c)) for a, b, c in zip(got, sp, ep)] == want, name

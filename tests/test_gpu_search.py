@@ -13,7 +13,7 @@ def _index_pair(oracle, gpu, n, seed=synth.GENOME_SEED, text=None):
     if text is None:
         text = oracle.gen_genome(n, seed)
     fo = oracle.make_fmi(text, n)
-    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     return text, fo, ix
 
 
@@ -96,7 +96,7 @@ def test_locate_every_row_is_the_suffix_array(oracle, gpu, n):
     text = oracle.gen_genome(n, synth.GENOME_SEED)
     sa = oracle.histsort(text, n)
     fo = oracle.make_fmi(text, n, sa)
-    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
     pos, steps = ix.locate_rows(rows, count_steps=True)
     np.testing.assert_array_equal(gpu.to_numpy_u32(pos), sa)
@@ -125,7 +125,7 @@ def test_tandem_repeat_index(oracle, gpu):
     text = oracle.gen_tandem(n, 7, 11)
     sa = oracle.sa_doubling(text, n)
     fo = oracle.make_fmi(text, n, sa)
-    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     np.testing.assert_array_equal(ix.rank_rows16(), fo.rank_rows)
     reads, _ = oracle.gen_reads(text, n, 4000, 30, 5)
     sp_o, ep_o = oracle.search_batch(fo, reads, 30, 30, 4000)
@@ -194,7 +194,7 @@ def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R
     bases = synth.unpack(text, n)
     fo = oracle.make_fmi(text, n, oracle.sa_doubling(text, n) if kind != "random" else None)
     full = gpu.build_index(text, n)
-    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     full.prepare_search()  # the position records and the k-mer table are made on first search otherwise
     lean.prepare_search()
     assert full.device_bytes > lean.device_bytes + 8 * n
@@ -252,7 +252,7 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     fo = oracle.make_fmi(text, n)
     monkeypatch.setenv("BWT_MI355X_KMER", str(k))
     full = gpu.build_index(text, n)
-    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     full.prepare_search()  # the table is made on first search: make it while the size is forced
     lean.prepare_search()
     monkeypatch.delenv("BWT_MI355X_KMER")
@@ -291,7 +291,7 @@ def test_kmer_table_around_the_short_suffixes(oracle, gpu, k, tail, monkeypatch)
         fo = oracle.make_fmi(text, n)
         monkeypatch.setenv("BWT_MI355X_KMER", str(k))
         full = gpu.build_index(text, n)
-        lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+        lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
         full.prepare_search()  # the table is made on first search: make it while the size is forced
         lean.prepare_search()
         monkeypatch.delenv("BWT_MI355X_KMER")
@@ -334,7 +334,7 @@ def test_attach_text_to_a_loaded_index(oracle, gpu):
     n, R, m = 500000, 20000, 70
     text = oracle.gen_genome(n, 808)
     fo = oracle.make_fmi(text, n)
-    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     ix.prepare_search()
     lean_bytes = ix.device_bytes
     other = oracle.gen_genome(n, 809)
@@ -355,7 +355,7 @@ def test_attach_text_to_a_loaded_index(oracle, gpu):
     rows = torch.arange(0, n + 1, 5, dtype=torch.int64, device="cuda").to(torch.int32)
     np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n)[::5])
     # device-resident text
-    ix2 = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix2 = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     ix2.attach_text(torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda())
     sp2, ep2 = ix2.search(d, m, R)
     np.testing.assert_array_equal(gpu.to_numpy_u32(sp2), sp_o)

@@ -28,7 +28,7 @@ def test_static_search_equals_search_twice_in_a_row(oracle, gpu, built_from_text
     n = 200_003
     text = oracle.gen_genome(n, synth.GENOME_SEED)
     fo = oracle.make_fmi(text, n)
-    ix = gpu.build_index(text, n) if built_from_text else gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+    ix = gpu.build_index(text, n) if built_from_text else gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     # m = 600: the packed reads go through the scratch; m = 50: packed inside the kernel
     for m, R_big, R_small in ((600, 3000, 701), (50, 20000, 4099), (1000, 513, 64)):
         big = _reads(oracle, text, n, R_big, m, synth.READS_SEED + m)

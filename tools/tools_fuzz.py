@@ -85,16 +85,18 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
             sa = G.sa_build(t, n)
             assert np.array_equal(G.to_numpy_u32(sa), sa_o), "SA"
             full = G.build_index_dev(t, n)
-            lean = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)
+            lean = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
+            loaded = G.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs)  # recomputes suffix array and text on first search
             if rng.integers(0, 4):  # mostly: the search arrays made now, under the forced sizes; else by the first search
                 full.prepare_search()
                 lean.prepare_search()
+                loaded.prepare_search()
             assert full.endloc == fo.endloc and full.C == fo.C, "endloc/C"
             bwt, idxs = full.export()
             assert np.array_equal(bwt, fo.bwt) and np.array_equal(idxs, fo.idxs), "export"
             assert np.array_equal(full.rank_rows16(), fo.rank_rows), "rank rows"
             rows = torch.arange(0, n + 1, dtype=torch.int64, device="cuda").to(torch.int32)
-            for ix in (full, lean):
+            for ix in (full, lean, loaded):
                 assert np.array_equal(G.to_numpy_u32(ix.locate_rows(rows)), sa_o), "locate"
             # sharded
             if n > 4096:
@@ -117,7 +119,7 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 sp_o, ep_o = orc.search_batch(fo, reads, m, m, R)
                 want_loc = [orc.locate(fo, reads[r]) for r in range(R)]
                 d = torch.from_numpy(reads.reshape(-1)).cuda()
-                for name, ix in (("full", full), ("lean", lean)):
+                for name, ix in (("full", full), ("lean", lean), ("loaded", loaded)):
                     sp, ep, lr = (G.to_numpy_u32(x) for x in ix.search(d, m, R, want_locrow=True))
                     assert np.array_equal(sp, sp_o) and np.array_equal(ep, ep_o), f"search {name} m={m}"
                     pos = G.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda())).astype(np.int64)
@@ -125,7 +127,7 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                     assert pos.tolist() == want_loc, f"locate() {name} m={m}"
                 readsn = reads_for(rng, bases, n, 200, m, True)
                 want = [orc.mms(fo, readsn[r]) for r in range(200)]
-                for name, ix in (("full", full), ("lean", lean)):
+                for name, ix in (("full", full), ("lean", lean), ("loaded", loaded)):
                     assert mms_gpu(ix, readsn) == want, f"mms {name} m={m}"
             # search_reads anchor loop on reads of mixed lengths, with substitutions and N
             enc = []
@@ -148,7 +150,7 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
             d_f = torch.from_numpy(np.concatenate(enc)).cuda()
             d_r = torch.from_numpy(np.concatenate([e[::-1] for e in enc])).cuda()
             d_o = torch.from_numpy(offs.view(np.int64)).cuda()
-            for name, ix in (("full", full), ("lean", lean)):
+            for name, ix in (("full", full), ("lean", lean), ("loaded", loaded)):
                 out = torch.empty(len(enc) * 4, dtype=torch.int32, device="cuda")
                 _lib.check(_lib.load().bwtgpu_search_reads(ix.h, d_f.data_ptr(), d_r.data_ptr(), d_o.data_ptr(),
                                                            len(enc), anchor, out.data_ptr(), None))
@@ -173,14 +175,14 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 offs = np.zeros(len(al) + 1, np.int64); offs[1:] = np.cumsum([len(e) for e in al])
                 d_al = torch.from_numpy(np.concatenate(al + [np.zeros(1, np.uint8)])).cuda()
                 d_ao = torch.from_numpy(offs).cuda()
-                for name, ix in (("full", full), ("lean", lean)):
+                for name, ix in (("full", full), ("lean", lean), ("loaded", loaded)):
                     pos, ops, nops = G.align_reads(ix, t, d_al, d_ao, len(al), a_len, 160)
                     pos_h, ops_h, nops_h = pos.cpu().numpy(), ops.cpu().numpy(), G.to_numpy_u32(nops)
                     for r in range(len(al)):
                         o = 5 * int(offs[r]) + 64 * r
                         got = (int(pos_h[r]), ops_h[o:o + int(nops_h[r])].tobytes())
                         assert got == want[r], f"align {name} anchor={a_len} read {r} len {len(al[r])}: {got[0]} vs {want[r][0]}"
-            full.close(); lean.close()
+            full.close(); lean.close(); loaded.close()
         except AssertionError as e:
             raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')}: {e}") from e
         finally:
