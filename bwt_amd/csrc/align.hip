@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t align_base(const uint8_t *__restrict__ text,
 }
 
 __device__ __forceinline__ int64_t align_unc_sa(const IndexView &v, uint32_t row) {
-  return v.sa ? (int64_t)v.sa[row] : (int64_t)unc_sa_dev(v, row);
+  return v.sa ? (int64_t)__builtin_nontemporal_load(v.sa + row) : (int64_t)unc_sa_dev(v, row);
 }
 
 // room for the unit operations of a read of len bases

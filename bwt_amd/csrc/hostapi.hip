@@ -60,7 +60,7 @@ k_search_locate_few(IndexView v, CTab C, const uint8_t *__restrict__ pats, uint3
   ep_out[r] = ep;
   const uint32_t row = early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp);
   row_out[r] = row;
-  if (pos_out) pos_out[r] = row > v.n ? 0xFFFFFFFFu : (v.sa ? v.sa[row] : unc_sa_dev(v, row));
+  if (pos_out) pos_out[r] = row > v.n ? 0xFFFFFFFFu : (v.sa ? __builtin_nontemporal_load(v.sa + row) : unc_sa_dev(v, row));
 }
 
 // Occ(c, idx) on the packed BWT (no C, no $ adjustment): seq_rank, seqindex.c:91-111

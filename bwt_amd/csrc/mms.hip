@@ -110,7 +110,7 @@ k_search_reads(IndexView v, CTab C, const uint8_t *__restrict__ reads, const uin
       if (got >= anchor) {  // :119-127
         res[dir]++;
         len -= got;
-        res[2 + dir] = sp > v.n ? 0xFFFFFFFFu : v.sa ? v.sa[sp] : unc_sa_dev(v, sp);
+        res[2 + dir] = sp > v.n ? 0xFFFFFFFFu : v.sa ? __builtin_nontemporal_load(v.sa + sp) : unc_sa_dev(v, sp);
         hint = 0;
       } else {
         len -= 1;  // :130

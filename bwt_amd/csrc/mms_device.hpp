@@ -123,7 +123,7 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
     sp = start;
     ep = end;
     if (v.isa && end - start == 1) {
-      const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : v.sa[start];
+      const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : __builtin_nontemporal_load(v.sa + start);
       uint32_t k = 0;  // bases that agree with the text in front of pos
       if (WAVE) {
         const uint32_t lane = threadIdx.x & 63u;

@@ -201,7 +201,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   if (VERIFY && !early && i >= 0 && ep - sp == 1) {
     const uint32_t rem = (uint32_t)i + 1;  // read bases 0..i are still to be prepended
     // no rank step has moved sp since the table lookup exactly when the table's interval was the single row
-    const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : v.sa[sp];
+    const uint32_t pos = table_pos != 0xFFFFFFFFu ? table_pos : __builtin_nontemporal_load(v.sa + sp);
     if (COUNT) n_ent += table_pos != 0xFFFFFFFFu ? 1 : 2;  // the SA entry unless the table had it, and the one ISA entry read below
     const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
     // the highest read base j in [jmin, rem) that differs from text[pos - rem + j];
