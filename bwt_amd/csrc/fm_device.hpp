@@ -61,18 +61,26 @@ __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x
     // the last-level cache: the load goes past the caches, which then keep the
     // position records and rank blocks (46 Mbp: 16.0 -> 18.0 G reads/s).
     const uint32_t *e = v.kmer + 2ull * x;
-    const uint64_t mine = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(e));
-    sp = (uint32_t)mine;
-    pos = (uint32_t)(mine >> 32);
     if (v.kmer_sizebits) {  // the entry says how many rows, unless they are many
+      const uint64_t mine = __builtin_nontemporal_load(reinterpret_cast<const uint64_t *>(e));
+      sp = (uint32_t)mine;
+      pos = (uint32_t)(mine >> 32);
       const uint32_t posbits = 32u - v.kmer_sizebits, size = pos >> posbits;
       pos &= (1u << posbits) - 1u;
       if (size < (1u << v.kmer_sizebits) - 1u) {
         next_read = false;
         return sp + size;
       }
+      ep = e[2];
+    } else {
+      // no room for the size: the entry and the start of the next one in one 16-byte load
+      // (a load past the caches leaves no line behind for a second one to find)
+      typedef uint32_t u32x4_at_8 __attribute__((ext_vector_type(4), aligned(8)));
+      const auto q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_at_8 *>(e));
+      sp = q.x;
+      pos = q.y;
+      ep = q.z;
     }
-    ep = e[2];
   } else {
     // one 8-byte load at a 4-byte aligned address: both starts in one request
     typedef uint64_t u64_at_4 __attribute__((aligned(4)));

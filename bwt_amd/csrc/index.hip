@@ -527,7 +527,12 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   // bits of an entry's second word that text positions (0..n) leave free take the interval's size
   uint32_t posbits = 1;
   while (posbits < 32 && (ix->n >> posbits)) ++posbits;
-  const uint32_t sizebits = (W == 2 && 32 - posbits >= 2) ? (32 - posbits < 6 ? 32 - posbits : 6u) : 0u;
+  uint32_t sizebits = (W == 2 && 32 - posbits >= 2) ? (32 - posbits < 6 ? 32 - posbits : 6u) : 0u;
+  // BWT_MI355X_KMER_SIZEBITS=<b> takes fewer (0: none, as for texts of 2^30 bases and more; 1 means 0 too)
+  if (const char *e = getenv("BWT_MI355X_KMER_SIZEBITS")) {
+    const uint32_t want = (uint32_t)atoi(e);
+    if (want < sizebits) sizebits = want >= 2 ? want : 0u;
+  }
   // level j < K lives in tmp_a when K - 1 - j is even, in tmp_b otherwise
   auto buf = [&](uint32_t j) { return ((K - 1 - j) & 1u) ? tmp_b : tmp_a; };
   const IndexView v = view_of(ix);

@@ -251,11 +251,16 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     text = oracle.gen_genome(n, 4242)
     fo = oracle.make_fmi(text, n)
     monkeypatch.setenv("BWT_MI355X_KMER", str(k))
+    # entries of two-word tables hold the interval's size in up to six spare bits; none are spare
+    # for texts of 2^30 bases and more, which is forced here for two of the table sizes
+    if k in (5, 11):
+        monkeypatch.setenv("BWT_MI355X_KMER_SIZEBITS", "0" if k == 5 else "2")
     full = gpu.build_index(text, n)
     lean = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
     full.prepare_search()  # the table is made on first search: make it while the size is forced
     lean.prepare_search()
     monkeypatch.delenv("BWT_MI355X_KMER")
+    monkeypatch.delenv("BWT_MI355X_KMER_SIZEBITS", raising=False)
     assert full.kmer_table == ((k, 2) if k >= 2 else (0, 0)) and lean.kmer_table == ((k, 1) if k >= 2 else (0, 0))
     bases = synth.unpack(text, n)
     for m in (1, 4, 8, 9, 10, 11, 12, 16, 17, 23, 32, 33, 70):
@@ -283,6 +288,8 @@ def test_kmer_table_around_the_short_suffixes(oracle, gpu, k, tail, monkeypatch)
     starts except where rows of suffixes shorter than k lie between.  Every
     string of k and of k + 1 bases is searched on texts whose last bases make
     those rows fall before, between and after occupied intervals."""
+    if k in (3, 6):  # entries without the interval's size (see test_kmer_table_start_gives_the_same_intervals)
+        monkeypatch.setenv("BWT_MI355X_KMER_SIZEBITS", "0")
     rng = np.random.default_rng(len(tail) * 16 + k)
     for n in (len(tail), len(tail) + 1, 40, 3001):
         bases = rng.integers(0, 4, n).astype(np.uint8)
