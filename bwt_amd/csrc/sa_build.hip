@@ -1128,33 +1128,49 @@ k_ghead_identity(const Leaf *__restrict__ leaves, const uint8_t *__restrict__ le
 // Segments still above kLeafMax when the bucket levels stop: one tie group
 // each.  Suffixes shorter than `depth` got here through the zero padding; they
 // precede the rest of their segment, shortest first, and are final.  There are
-// fewer than `depth` of them in the whole text.
+// fewer than `depth` of them in the whole text.  A segment can be most of the
+// text (a tandem repeat of period 7 has seven), so its rows are dealt to
+// kUnresParts workgroups: k_unresolved_copy moves the rows, makes the segment one
+// group and lists the short suffixes; k_unresolved_short orders those few;
+// k_unresolved_heads moves the group's head behind them where there are any.
+constexpr uint32_t kUnresParts = 64;
+constexpr uint32_t kUnresList = kMaxDepth + 8;  // short[seg * (kUnresList + 1)]: count, then rows
+
 __global__ void __launch_bounds__(256)
-k_unresolved_segs(const Seg *__restrict__ segs, const uint32_t *__restrict__ src,
-                  uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint32_t depth,
-                  uint32_t n, Counters *__restrict__ ctr) {
-  __shared__ uint32_t short_rows[kMaxDepth + 8];
-  __shared__ uint32_t nshort;
-  const Seg sg = segs[blockIdx.x];
-  if (threadIdx.x == 0) nshort = 0;
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < sg.size; j += 256) {
+k_unresolved_copy(const Seg *__restrict__ segs, const uint32_t *__restrict__ src,
+                  uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint32_t depth, uint32_t n,
+                  uint32_t *__restrict__ shortl) {
+  const uint32_t seg = blockIdx.x / kUnresParts, part = blockIdx.x % kUnresParts;
+  const Seg sg = segs[seg];
+  const uint32_t slice = (sg.size + kUnresParts - 1) / kUnresParts;
+  const uint32_t lo = part * slice, hi = lo + slice < sg.size ? lo + slice : sg.size;
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += 256) {
     const uint32_t row = sg.start + j;
     const uint32_t id = src[row];
     sa_rows[row] = id;
+    ghead[1 + row] = 1 + sg.start;
     if ((uint64_t)id + depth > n) {
-      const uint32_t k = atomicAdd(&nshort, 1u);
-      if (k < kMaxDepth + 8) short_rows[k] = row;
+      const uint32_t k = atomicAdd(&shortl[(uint64_t)seg * (kUnresList + 1)], 1u);
+      if (k < kUnresList) shortl[(uint64_t)seg * (kUnresList + 1) + 1 + k] = row;
     }
   }
-  __syncthreads();
-  const uint32_t E = nshort;
-  if (threadIdx.x == 0 && E) {
+}
+
+__global__ void k_unresolved_short(const Seg *__restrict__ segs, uint32_t *__restrict__ sa_rows,
+                                   uint32_t *__restrict__ ghead, uint32_t depth, uint32_t n,
+                                   const uint32_t *__restrict__ shortl, uint32_t nsegs,
+                                   Counters *__restrict__ ctr) {
+  const uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= nsegs) return;
+  const Seg sg = segs[seg];
+  const uint32_t *mine = shortl + (uint64_t)seg * (kUnresList + 1);
+  const uint32_t E = mine[0] < kUnresList ? mine[0] : kUnresList;
+  if (E) {
     // move the short suffixes to the first E rows (the order of the others is
     // free), then order them by decreasing start
     uint32_t lo = sg.start;
     for (uint32_t k = 0; k < E; ++k) {
-      const uint32_t r = short_rows[k];
+      const uint32_t r = mine[1 + k];
       if (r < sg.start + E) continue;  // already in the front part
       while ((uint64_t)sa_rows[lo] + depth > n) ++lo;  // first front row holding a long suffix
       const uint32_t tmp = sa_rows[lo];
@@ -1171,14 +1187,25 @@ k_unresolved_segs(const Seg *__restrict__ segs, const uint32_t *__restrict__ src
       }
       sa_rows[sg.start + b] = v;
     }
+    for (uint32_t j = 0; j < E; ++j) ghead[1 + sg.start + j] = 1 + sg.start + j;
   }
-  __syncthreads();
-  for (uint32_t j = threadIdx.x; j < sg.size; j += 256)
-    ghead[1 + sg.start + j] = j < E ? 1 + sg.start + j : 1 + sg.start + E;
-  if (threadIdx.x == 0 && sg.size - E >= 2) {
+  if (sg.size - E >= 2) {
     atomicAdd(&ctr->unresolved, sg.size - E);
     atomicMin(&ctr->min_depth, depth);
   }
+}
+
+__global__ void __launch_bounds__(256)
+k_unresolved_heads(const Seg *__restrict__ segs, uint32_t *__restrict__ ghead, const uint32_t *__restrict__ shortl) {
+  const uint32_t seg = blockIdx.x / kUnresParts, part = blockIdx.x % kUnresParts;
+  const uint32_t *mine = shortl + (uint64_t)seg * (kUnresList + 1);
+  const uint32_t E = mine[0] < kUnresList ? mine[0] : kUnresList;
+  if (!E) return;  // the head k_unresolved_copy wrote stands
+  const Seg sg = segs[seg];
+  const uint32_t slice = (sg.size + kUnresParts - 1) / kUnresParts;
+  const uint32_t lo = part * slice, hi = lo + slice < sg.size ? lo + slice : sg.size;
+  for (uint32_t j = lo + threadIdx.x; j < hi; j += 256)
+    if (j >= E) ghead[1 + sg.start + j] = 1 + sg.start + E;
 }
 
 // ---- prefix doubling over the remaining tie groups -------------------------------
@@ -1303,6 +1330,692 @@ static int sa_doubling(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0,
                             scanws.p, scan_workspace_bytes(rows), s));
     BWT_LAUNCH("dbl_apply", k_doubling_apply, dim3(ga), dim3(256), 0, s, V.as<uint32_t>(),
                rowof.as<uint32_t>(), hv.as<uint32_t>(), A, d_sa, ghead, isa.as<uint32_t>());
+    BWT_CHECK_LAUNCH();
+    h *= 2;
+  }
+  return set_error(kErrInternal, "prefix doubling did not converge");
+}
+
+// ---- prefix doubling, group by group ---------------------------------------------
+//
+// The tie groups are runs of neighbouring rows, so a doubling round never has to
+// sort across groups: rows only move inside their group.  A round with offset h
+//   1. notes, per tile of kDblTile rows, the first and last group head in it and
+//      (k_dbl_next_head) the first head after it: enough to know every group's size;
+//   2. gathers the key of every row still tied, rank[start + h]       (k_dbl_keys);
+//   3. splits groups of more than kDblTile rows by an 8-bit digit of the key,
+//      interpolated between the group's smallest and largest key, level by
+//      level until the pieces are small or hold one key         (k_dbl_hist, .._scatter);
+//   4. sorts every group of up to kDblTile rows in LDS and gives equal keys a
+//      group of their own                                            (k_dbl_small).
+// The rank of a suffix is a label of its group: some row of the group, the first
+// one to begin with.  When a group splits, the piece that holds the label's row
+// keeps the label and the others take their first row -- labels stay in row
+// order, and a piece of more than half the group (what a repeat leaves when a
+// few suffixes part from it) keeps its label wherever it lies, so that ranks
+// are rewritten for the rows that parted only.  Against one stable 64-bit LSD
+// sort of (group, key) over all tied rows per round, a row moves once or twice
+// per round instead of seven times.
+
+constexpr uint32_t kDblTile = 2048;           // rows per tile; a group of up to this many rows is sorted in LDS
+constexpr uint32_t kDblChunk = 4096;          // rows a partition workgroup holds at a time (256 threads x 16)
+constexpr uint32_t kDblChunks = 4;            // ... and chunks it takes one after the other: one claim of room for all
+constexpr uint32_t kDblPart = kDblChunk * kDblChunks;
+constexpr uint32_t kDblPartThreads = 256;
+constexpr uint32_t kDblItems = kDblChunk / kDblPartThreads;
+constexpr uint32_t kDblNone = 0xFFFFFFFFu;
+
+struct DblCtr {
+  uint32_t active;       // rows in groups of two or more
+  uint32_t nbig;         // groups of more than kDblTile rows found by k_dbl_emit_big
+  uint32_t nnext;        // pieces of more than kDblTile rows the current level left
+  uint32_t total_tiles;  // partition tiles of the current level
+};
+
+__global__ void k_dbl_init(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ ghead,
+                           uint32_t *__restrict__ isa, uint32_t *__restrict__ glabel, uint64_t rows) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows) return;
+  isa[sa[j]] = ghead[j];
+  glabel[j] = (uint32_t)j;  // read at group heads only
+}
+
+__global__ void __launch_bounds__(256)
+k_dbl_tiles(const uint32_t *__restrict__ ghead, uint64_t rows, uint32_t *__restrict__ first_head,
+            uint32_t *__restrict__ last_head, uint32_t *__restrict__ tied_rows) {
+  static_assert(kDblTile == 256 * 8, "eight consecutive rows per thread");
+  __shared__ uint32_t lo, hi, act;
+  if (threadIdx.x == 0) {
+    lo = kDblNone;
+    hi = 0;
+    act = 0;
+  }
+  __syncthreads();
+  const uint64_t r0 = (uint64_t)blockIdx.x * kDblTile + 8ull * threadIdx.x;
+  uint32_t g[9];
+  if (r0 + 9 <= rows) {  // ghead is 16-byte aligned and so is every thread's first row
+    const uint4 a = reinterpret_cast<const uint4 *>(ghead + r0)[0], b = reinterpret_cast<const uint4 *>(ghead + r0)[1];
+    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
+    g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+    g[8] = ghead[r0 + 8];
+  } else {
+#pragma unroll
+    for (uint32_t k = 0; k < 9; ++k) g[k] = r0 + k < rows ? ghead[r0 + k] : kDblNone;  // no row has this head
+  }
+  uint32_t mylo = kDblNone, myhi = 0, mine = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint64_t j = r0 + k;
+    if (j < rows) {
+      if (g[k] == (uint32_t)j) {
+        mylo = mylo == kDblNone ? (uint32_t)j : mylo;
+        myhi = (uint32_t)j;
+        mine += g[k + 1] == (uint32_t)j ? 1u : 0u;
+      } else {
+        ++mine;
+      }
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    const uint32_t x = __shfl_xor(mylo, off, 64), y = __shfl_xor(myhi, off, 64);
+    mylo = x < mylo ? x : mylo;
+    myhi = y > myhi ? y : myhi;
+    mine += __shfl_xor(mine, off, 64);
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    if (mylo != kDblNone) {
+      atomicMin(&lo, mylo);
+      atomicMax(&hi, myhi);
+    }
+    if (mine) atomicAdd(&act, mine);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    first_head[blockIdx.x] = lo;
+    last_head[blockIdx.x] = lo == kDblNone ? kDblNone : hi;
+    tied_rows[blockIdx.x] = act;  // summed by k_dbl_next_head: one counter for all tiles would serialise them
+  }
+}
+
+// nxt[i] = the first group head in a tile after tile i, `rows` if there is none;
+// also the sum of the tiles' tied rows
+__global__ void __launch_bounds__(1024)
+k_dbl_next_head(const uint32_t *__restrict__ first_head, const uint32_t *__restrict__ tied_rows, uint32_t ntiles,
+                uint32_t rows, uint32_t *__restrict__ nxt, DblCtr *__restrict__ ctr) {
+  __shared__ uint32_t wmin[16], wsum[16];
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  uint32_t carry = rows, tied = 0;
+  for (int64_t base = (int64_t)((ntiles - 1) / 1024u) * 1024; base >= 0; base -= 1024) {
+    const uint64_t i = (uint64_t)base + t;
+    const uint32_t v = i < ntiles ? first_head[i] : kDblNone;
+    tied += i < ntiles ? tied_rows[i] : 0u;
+    uint32_t s = v;  // smallest of lanes lane.. of the wave
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_down(s, off, 64);
+      if (lane + off < 64 && u < s) s = u;
+    }
+    if (lane == 0) wmin[wave] = s;
+    __syncthreads();
+    uint32_t after = carry;
+    for (uint32_t w = wave + 1; w < 16; ++w) after = wmin[w] < after ? wmin[w] : after;
+    uint32_t ex = __shfl_down(s, 1, 64);
+    if (lane == 63) ex = kDblNone;
+    if (i < ntiles) nxt[i] = ex < after ? ex : after;
+    uint32_t all = carry;
+    for (uint32_t w = 0; w < 16; ++w) all = wmin[w] < all ? wmin[w] : all;
+    carry = all;
+    __syncthreads();
+  }
+  for (int off = 32; off; off >>= 1) tied += __shfl_down(tied, off, 64);
+  if (lane == 0) wsum[wave] = tied;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 16; ++w) total += wsum[w];
+    ctr->active = total;
+  }
+}
+
+// groups of more than kDblTile rows: only the last head of a tile can start one
+__global__ void k_dbl_emit_big(const uint32_t *__restrict__ last_head, const uint32_t *__restrict__ nxt,
+                               uint32_t ntiles, Seg *__restrict__ segs, uint32_t cap, DblCtr *__restrict__ ctr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles) return;
+  const uint32_t j = last_head[i];
+  if (j == kDblNone) return;
+  const uint32_t size = nxt[i] - j;
+  if (size <= kDblTile) return;
+  const uint32_t k = atomicAdd(&ctr->nbig, 1u);
+  if (k < cap) segs[k] = Seg{j, size};
+}
+
+__global__ void k_dbl_keys(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ ghead,
+                           const uint32_t *__restrict__ isa, uint32_t n, uint64_t h, uint64_t rows,
+                           uint32_t *__restrict__ key) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= rows) return;
+  const bool tied = ghead[j] != (uint32_t)j || (j + 1 < rows && ghead[j + 1] == (uint32_t)j);
+  if (!tied) return;
+  // a suffix in a tie group shares at least h bases with another, so start + h <= n;
+  // rank 0 is the end-of-text suffix and orders a suffix that ends exactly there first
+  const uint64_t nx = (uint64_t)sa[j] + h;
+  key[j] = nx <= n ? isa[nx] : 0u;
+}
+
+// --- groups of more than kDblTile rows: one 8-bit split per level ---
+
+__global__ void k_dbl_seg_tiles(const Seg *__restrict__ segs, uint32_t nsegs, uint32_t *__restrict__ tiles,
+                                uint32_t *__restrict__ mm) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsegs) return;
+  tiles[s] = (segs[s].size + kDblPart - 1) / kDblPart;
+  mm[2 * s] = 0xFFFFFFFFu;
+  mm[2 * s + 1] = 0u;
+}
+
+// a partition tile is up to kDblPart rows of one group
+__device__ __forceinline__ bool dbl_locate_tile(uint32_t tile, const Seg *segs, const uint32_t *tile_first,
+                                                uint32_t nsegs, const DblCtr *ctr, TileInfo *sh) {
+  if (threadIdx.x == 0) {
+    if (tile >= ctr->total_tiles) {
+      sh->count = 0;
+    } else {
+      const uint32_t s = find_segment(tile_first, nsegs, tile);
+      const Seg sg = segs[s];
+      const uint32_t off = (tile - tile_first[s]) * kDblPart;
+      sh->seg = s;
+      sh->row0 = sg.start + off;
+      const uint32_t left = sg.size - off;
+      sh->count = left < kDblPart ? left : kDblPart;
+    }
+  }
+  __syncthreads();
+  return sh->count != 0;
+}
+
+__global__ void __launch_bounds__(kDblPartThreads)
+k_dbl_minmax(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+             const DblCtr *__restrict__ ctr, const uint32_t *__restrict__ key, uint32_t *__restrict__ mm) {
+  __shared__ TileInfo ti;
+  __shared__ uint32_t lo, hi;
+  if (threadIdx.x == 0) {
+    lo = 0xFFFFFFFFu;
+    hi = 0;
+  }
+  if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
+  uint32_t a = 0xFFFFFFFFu, b = 0;
+  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
+      if (k < ti.count) {
+        const uint32_t v = key[ti.row0 + k];
+        a = v < a ? v : a;
+        b = v > b ? v : b;
+      }
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    const uint32_t x = __shfl_xor(a, off, 64), y = __shfl_xor(b, off, 64);
+    a = x < a ? x : a;
+    b = y > b ? y : b;
+  }
+  if ((threadIdx.x & 63u) == 0) {
+    atomicMin(&lo, a);
+    atomicMax(&hi, b);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&mm[2 * ti.seg], lo);
+    atomicMax(&mm[2 * ti.seg + 1], hi);
+  }
+}
+
+// the digit of a key inside a group whose keys span [lo, hi], lo < hi: monotone in
+// the key, and lo and hi never share a digit, so every level splits its group
+__device__ __forceinline__ uint32_t dbl_digit(uint32_t key, uint32_t lo, float scale) {
+  const uint32_t d = (uint32_t)((float)(key - lo) * scale);
+  return d < 255u ? d : 255u;
+}
+__device__ __forceinline__ float dbl_scale(uint32_t lo, uint32_t hi) {
+  return 256.0f / ((float)(hi - lo) + 1.0f);
+}
+
+// Adds one to counter[d] for every lane with `valid`, one LDS atomic per distinct digit
+// of the wave: when nearly all keys of a group are equal (what a repeat looks like) the
+// lanes of a wave would otherwise queue on one address.  Returns the lane's place among
+// the increments of its digit.  Every lane of the wave calls it.
+__device__ __forceinline__ uint32_t dbl_count(uint32_t *counter, uint32_t d, bool valid, uint32_t lane) {
+  uint64_t same = __ballot(valid);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t bal = __ballot(bit);
+    same &= bit ? bal : ~bal;
+  }
+  const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+  uint32_t first = 0;
+  if (valid && before == 0) first = atomicAdd(&counter[d], (uint32_t)__popcll(same));
+  const int leader = valid ? __ffsll((long long)same) - 1 : (int)lane;
+  first = __shfl(first, leader, 64);
+  return first + before;
+}
+
+__global__ void __launch_bounds__(kDblPartThreads)
+k_dbl_hist(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+           const DblCtr *__restrict__ ctr, const uint32_t *__restrict__ key, const uint32_t *__restrict__ mm,
+           uint32_t *__restrict__ counts) {
+  __shared__ TileInfo ti;
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
+  const uint32_t lo = mm[2 * ti.seg], hi = mm[2 * ti.seg + 1];
+  if (lo >= hi) return;  // one key: the group stays as it is this round
+  const float scale = dbl_scale(lo, hi);
+  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
+      const bool valid = k < ti.count;
+      const uint32_t d = valid ? dbl_digit(key[ti.row0 + k], lo, scale) : 0u;
+      dbl_count(hist, d, valid, threadIdx.x & 63u);
+    }
+  }
+  __syncthreads();
+  const uint32_t c = hist[threadIdx.x];
+  if (c) atomicAdd(&counts[(uint64_t)ti.seg * 256 + threadIdx.x], c);
+}
+
+// counts -> first rows of the 256 pieces (cursors for the scatter, and a copy that
+// stays) and their labels; pieces of more than kDblTile rows go on to the next level
+__global__ void __launch_bounds__(256)
+k_dbl_classify(const Seg *__restrict__ segs, uint32_t nsegs, const uint32_t *__restrict__ mm,
+               uint32_t *__restrict__ counts, uint32_t *__restrict__ piece_start, uint32_t *__restrict__ piece_label,
+               uint32_t *__restrict__ glabel, Seg *__restrict__ next_segs, uint32_t cap, DblCtr *__restrict__ ctr) {
+  __shared__ uint32_t wsum[4];
+  const uint32_t s = blockIdx.x, t = threadIdx.x;
+  if (mm[2 * s] >= mm[2 * s + 1]) return;
+  const Seg sg = segs[s];
+  const uint32_t label = glabel[sg.start];  // every thread reads it before the barrier, the pieces' are written after
+  const uint32_t c = counts[(uint64_t)s * 256 + t];
+  uint32_t v = c;
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
+  }
+  if (lane == 63) wsum[wave] = v;
+  __syncthreads();
+  uint32_t pre = 0;
+  for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+  const uint32_t start = sg.start + pre + v - c;
+  counts[(uint64_t)s * 256 + t] = start;
+  piece_start[(uint64_t)s * 256 + t] = start;
+  // the piece that holds the row the group's label names keeps the label; another takes its
+  // middle row, so that it keeps that label as long as it loses less than half its rows
+  // from either end (a repeat sheds a few suffixes per round, mostly from the front)
+  const uint32_t mine = (label >= start && label - start < c) ? label : start + c / 2;
+  piece_label[(uint64_t)s * 256 + t] = mine;
+  if (c) glabel[start] = mine;
+  if (c > kDblTile) {
+    const uint32_t k = atomicAdd(&ctr->nnext, 1u);
+    if (k < cap) next_segs[k] = Seg{start, c};
+  }
+}
+
+// A workgroup takes a tile chunk by chunk: first the tile's digit counts and one
+// claim of room per digit for all of it (with one group making up most of the text,
+// a claim per chunk would queue tens of thousands of workgroups on one counter),
+// then each chunk goes into bucket order in LDS and out.
+__global__ void __launch_bounds__(kDblPartThreads)
+k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+              const DblCtr *__restrict__ ctr, const uint32_t *__restrict__ sa, const uint32_t *__restrict__ key,
+              const uint32_t *__restrict__ mm, uint32_t *__restrict__ cursors,
+              const uint32_t *__restrict__ piece_start, const uint32_t *__restrict__ piece_label,
+              const uint32_t *__restrict__ glabel_old /* label of the group, read before k_dbl_classify ran */,
+              uint32_t *__restrict__ dst_sa, uint32_t *__restrict__ dst_key, uint32_t *__restrict__ ghead,
+              uint32_t *__restrict__ isa) {
+  __shared__ TileInfo ti;
+  __shared__ uint32_t hist[256], lstart[256], gbase[256], pstart[256], plabel[256], wsum[4];
+  __shared__ uint32_t ids[kDblChunk], kv[kDblChunk];
+  __shared__ uint8_t dig[kDblChunk];
+  const uint32_t t = threadIdx.x;
+  hist[t] = 0;
+  if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
+  const uint32_t lo = mm[2 * ti.seg], hi = mm[2 * ti.seg + 1];
+  if (lo >= hi) return;
+  const float scale = dbl_scale(lo, hi);
+  const uint32_t row0 = ti.row0, count = ti.count;
+  const uint32_t old_label = glabel_old[ti.seg];
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  for (uint32_t c0 = 0; c0 < count; c0 += kDblChunk) {
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t j = c0 + i * kDblPartThreads + t;
+      const bool valid = j < count;
+      const uint32_t d = valid ? dbl_digit(key[row0 + j], lo, scale) : 0u;
+      dbl_count(hist, d, valid, lane);
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t c = hist[t];
+    gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
+    pstart[t] = piece_start[(uint64_t)ti.seg * 256 + t];
+    plabel[t] = piece_label[(uint64_t)ti.seg * 256 + t];
+  }
+  for (uint32_t c0 = 0; c0 < count; c0 += kDblChunk) {
+    const uint32_t cc = count - c0 < kDblChunk ? count - c0 : kDblChunk;
+    __syncthreads();  // the chunk before has been written out; the claims have landed
+    hist[t] = 0;
+    __syncthreads();
+    uint32_t id[kDblItems], kk[kDblItems], dd[kDblItems], place[kDblItems];
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t j = i * kDblPartThreads + t;
+      const bool valid = j < cc;
+      id[i] = valid ? sa[row0 + c0 + j] : 0u;
+      kk[i] = valid ? key[row0 + c0 + j] : 0u;
+      dd[i] = valid ? dbl_digit(kk[i], lo, scale) : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i)
+      place[i] = dbl_count(hist, dd[i], i * kDblPartThreads + t < cc, lane);  // its place among the chunk's rows of that digit
+    __syncthreads();
+    const uint32_t c = hist[t];
+    uint32_t v = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+    lstart[t] = pre + v - c;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      if (i * kDblPartThreads + t < cc) {
+        const uint32_t p = lstart[dd[i]] + place[i];
+        ids[p] = id[i];
+        kv[p] = kk[i];
+        dig[p] = (uint8_t)dd[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t j = i * kDblPartThreads + t;
+      if (j < cc) {
+        const uint32_t d = dig[j];
+        const uint32_t pos = gbase[d] + (j - lstart[d]);
+        dst_sa[pos] = ids[j];
+        dst_key[pos] = kv[j];
+        ghead[pos] = pstart[d];
+        if (plabel[d] != old_label) isa[ids[j]] = plabel[d];
+      }
+    }
+    __syncthreads();
+    gbase[t] += c;  // the chunk's share of the claim is used up
+  }
+}
+
+__global__ void k_dbl_old_labels(const Seg *__restrict__ segs, uint32_t nsegs, const uint32_t *__restrict__ glabel,
+                                 uint32_t *__restrict__ out) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nsegs) out[s] = glabel[segs[s].start];
+}
+
+__global__ void __launch_bounds__(kDblPartThreads)
+k_dbl_copyback(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
+               const DblCtr *__restrict__ ctr, const uint32_t *__restrict__ mm, const uint32_t *__restrict__ src_sa,
+               const uint32_t *__restrict__ src_key, uint32_t *__restrict__ sa, uint32_t *__restrict__ key) {
+  __shared__ TileInfo ti;
+  if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
+  if (mm[2 * ti.seg] >= mm[2 * ti.seg + 1]) return;
+  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
+#pragma unroll
+    for (uint32_t i = 0; i < kDblItems; ++i) {
+      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
+      if (k < ti.count) {
+        sa[ti.row0 + k] = src_sa[ti.row0 + k];
+        key[ti.row0 + k] = src_key[ti.row0 + k];
+      }
+    }
+  }
+}
+
+// --- groups of up to kDblTile rows: every tile's workgroup sorts the groups that
+// start in its tile (they end within the next tile) by (group, key) in LDS ---
+
+template <int LOGE>
+__device__ __forceinline__ void dbl_sort_words(const uint32_t *__restrict__ ghl, const uint32_t *__restrict__ key,
+                                               uint32_t base, uint32_t cnt, uint64_t *lds, uint32_t t) {
+  constexpr int E = 1 << LOGE;
+  uint64_t r[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t j = t * E + m;
+    r[m] = ~0ull;
+    if (j < cnt) {
+      const uint32_t g = ghl[j];
+      const bool tied = g != base + j || (j + 1 < cnt && ghl[j + 1] == base + j);
+      const uint32_t k = tied ? key[base + j] : 0u;
+      r[m] = ((uint64_t)(g - base) << 52) | ((uint64_t)k << 20) | j;
+    }
+  }
+  leaf_bitonic<LOGE>(r, lds, t);
+#pragma unroll
+  for (int m = 0; m < E; ++m) lds[pad(t * E + m)] = r[m];
+}
+
+__global__ void __launch_bounds__(kLeafThreads, 2)
+k_dbl_small(const uint32_t *__restrict__ first_head, const uint32_t *__restrict__ last_head,
+            const uint32_t *__restrict__ nxt, uint32_t *__restrict__ sa, const uint32_t *__restrict__ key,
+            uint32_t *__restrict__ ghead, uint32_t *__restrict__ isa, uint32_t *__restrict__ glabel) {
+  constexpr uint32_t kWin = 2 * kDblTile;
+  static_assert(kWin == (uint32_t)kLeafThreads * 8, "eight rows per thread");
+  __shared__ uint64_t words[kWin + kWin / 32 + 1];
+  __shared__ uint32_t ghl[kWin];  // heads of the window's rows, then the starts of its suffixes
+  __shared__ uint32_t wmax[kLeafWaves];
+  __shared__ uint32_t anytied;
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = first_head[blockIdx.x];
+  if (base == kDblNone) return;
+  const uint32_t lastg = last_head[blockIdx.x], e = nxt[blockIdx.x];
+  const uint32_t end = e - lastg <= kDblTile ? e : lastg;  // a longer last group is not this kernel's
+  const uint32_t cnt = end - base;                        // < kWin
+  if (cnt == 0) return;
+  if (t == 0) anytied = 0;
+  __syncthreads();
+  bool tied = false;
+  for (uint32_t j = t; j < cnt; j += kLeafThreads) {
+    const uint32_t g = ghead[base + j];
+    ghl[j] = g;
+    tied = tied || g != base + j;
+  }
+  if (tied) anytied = 1;
+  __syncthreads();
+  if (!anytied) return;  // every row of the range is settled
+  uint32_t P = 2 * kLeafThreads;
+  while (P < cnt) P <<= 1;
+  if (P == 8 * kLeafThreads) dbl_sort_words<3>(ghl, key, base, cnt, words, t);
+  else if (P == 4 * kLeafThreads) dbl_sort_words<2>(ghl, key, base, cnt, words, t);
+  else dbl_sort_words<1>(ghl, key, base, cnt, words, t);
+  __syncthreads();
+  // the suffix starts take the place of the heads (which the words now hold)
+  for (uint32_t j = t; j < cnt; j += kLeafThreads) ghl[j] = sa[base + j];
+  __syncthreads();
+  // blocked: thread t owns sorted places [t * per, t * per + per)
+  const uint32_t per = P / kLeafThreads;
+  const uint32_t j0 = t * per;
+  uint64_t w[9];
+  uint32_t hv[8], local_max = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < 9; ++k) {
+    const uint32_t j = j0 + k - 1u;
+    w[k] = (k <= per && j < cnt) ? words[pad(j)] : ~0ull;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint32_t j = j0 + k;
+    hv[k] = 0;
+    if (k < per && j < cnt) {
+      const bool same = j > 0 && (w[k] >> 20) == (w[k + 1] >> 20);  // same group, same key as the row before
+      hv[k] = same ? 0u : base + j;
+      local_max = hv[k] > local_max ? hv[k] : local_max;
+    }
+  }
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  uint32_t v = local_max;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v = u > v ? u : v;
+  }
+  if (lane == 63) wmax[wave] = v;
+  __syncthreads();  // also: every thread has read its window of words
+  uint32_t run = 0;
+  for (uint32_t q = 0; q < wave; ++q) run = wmax[q] > run ? wmax[q] : run;
+  const uint32_t up = __shfl_up(v, 1, 64);
+  if (lane) run = up > run ? up : run;
+  // the new head of every place, where its neighbours can see it (in the words' room),
+  // and the label of the group each row came from
+  uint32_t *newhead = reinterpret_cast<uint32_t *>(words);
+  uint32_t nh[8], lab[8];
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint32_t j = j0 + k;
+    nh[k] = lab[k] = 0;
+    if (k < per && j < cnt) {
+      run = hv[k] > run ? hv[k] : run;
+      nh[k] = run;
+      newhead[j] = run;
+      lab[k] = glabel[base + (uint32_t)(w[k + 1] >> 52)];
+    }
+  }
+  __syncthreads();  // every old label has been read before a new one is written
+#pragma unroll
+  for (uint32_t k = 0; k < 8; ++k) {
+    const uint32_t j = j0 + k;
+    if (k < per && j < cnt) {
+      const uint64_t cur = w[k + 1];
+      const uint32_t id = ghl[(uint32_t)cur & 0xFFFFFu];
+      const uint32_t old = base + (uint32_t)(cur >> 52);
+      // the piece that holds the row the old group's label names keeps the label
+      const uint32_t mine = newhead[lab[k] - base] == nh[k] ? lab[k] : nh[k];
+      sa[base + j] = id;
+      if (nh[k] != old) ghead[base + j] = nh[k];
+      if (nh[k] == base + j) glabel[base + j] = mine;
+      if (mine != lab[k]) isa[id] = mine;
+    }
+  }
+}
+
+static int sa_doubling_groups(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0, hipStream_t s);
+
+// BWT_MI355X_DOUBLING=lsd: the rounds as one 64-bit radix sort each (sa_doubling), kept for comparison
+static int sa_finish_ties(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0, uint32_t *flags,
+                          Counters *d_ctr, hipStream_t s) {
+  const char *e = getenv("BWT_MI355X_DOUBLING");
+  if (e && !strcmp(e, "lsd")) return sa_doubling(d_sa, ghead, n, h0, flags, d_ctr, s);
+  return sa_doubling_groups(d_sa, ghead, n, h0, s);
+}
+
+static int sa_doubling_groups(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint32_t h0, hipStream_t s) {
+  const uint64_t rows = (uint64_t)n + 1;
+  const uint32_t ntiles = (uint32_t)div_up(rows, kDblTile);
+  const uint32_t cap = (uint32_t)(rows / kDblTile) + 16;  // groups of more than kDblTile rows
+  DevBuf isa, key, alt_sa, alt_key, glabel, heads, segs_a, segs_b, mm, counts, pieces, plabels, oldl, tiles, scanws, dctr;
+  hipError_t e = isa.alloc(rows * 4);
+  if (e == hipSuccess) e = key.alloc(rows * 4);
+  if (e == hipSuccess) e = alt_sa.alloc(rows * 4);
+  if (e == hipSuccess) e = alt_key.alloc(rows * 4);
+  if (e == hipSuccess) e = glabel.alloc(rows * 4);
+  if (e == hipSuccess) e = heads.alloc((size_t)ntiles * 4 * 4);
+  if (e == hipSuccess) e = segs_a.alloc((size_t)cap * sizeof(Seg));
+  if (e == hipSuccess) e = segs_b.alloc((size_t)cap * sizeof(Seg));
+  if (e == hipSuccess) e = mm.alloc((size_t)cap * 8);
+  if (e == hipSuccess) e = counts.alloc((size_t)cap * 256 * 4);
+  if (e == hipSuccess) e = pieces.alloc((size_t)cap * 256 * 4);
+  if (e == hipSuccess) e = plabels.alloc((size_t)cap * 256 * 4);
+  if (e == hipSuccess) e = oldl.alloc((size_t)cap * 4);
+  if (e == hipSuccess) e = tiles.alloc(((size_t)cap + 1) * 4);
+  if (e == hipSuccess) e = scanws.alloc(scan_workspace_bytes((uint64_t)cap + 1));
+  if (e == hipSuccess) e = dctr.alloc(256);
+  if (e != hipSuccess) return set_error(kErrHip, "prefix doubling buffers: %s", hipGetErrorString(e));
+  uint32_t *first_head = heads.as<uint32_t>(), *last_head = first_head + ntiles, *nxt = last_head + ntiles,
+           *tied_rows = nxt + ntiles;
+  DblCtr *ctr = dctr.as<DblCtr>();
+  const unsigned gr = (unsigned)div_up(rows, 256);
+  BWT_LAUNCH("dbl_init", k_dbl_init, dim3(gr), dim3(256), 0, s, d_sa, ghead, isa.as<uint32_t>(), glabel.as<uint32_t>(),
+             rows);
+  auto survey = [&]() -> int {  // heads per tile, then the first head after every tile
+    BWT_LAUNCH("dbl_tiles", k_dbl_tiles, dim3(ntiles), dim3(256), 0, s, ghead, rows, first_head, last_head, tied_rows);
+    BWT_LAUNCH("dbl_next_head", k_dbl_next_head, dim3(1), dim3(1024), 0, s, first_head, tied_rows, ntiles,
+               (uint32_t)rows, nxt, ctr);
+    return kOk;
+  };
+  uint64_t h = h0 ? h0 : 1;
+  uint32_t prev_active = 0xFFFFFFFFu;
+  for (int round = 0; round < 64; ++round) {
+    BWT_HIP(hipMemsetAsync(ctr, 0, sizeof(DblCtr), s));
+    BWT_TRY(survey());
+    BWT_LAUNCH("dbl_emit_big", k_dbl_emit_big, dim3((unsigned)div_up(ntiles, 256)), dim3(256), 0, s, last_head, nxt,
+               ntiles, segs_a.as<Seg>(), cap, ctr);
+    DblCtr hc;
+    BWT_HIP(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, s));
+    BWT_HIP(hipStreamSynchronize(s));
+    if (hc.active == 0) {
+      g_stats.v[3] = round;
+      return kOk;
+    }
+    if (hc.active > prev_active)
+      return set_error(kErrInternal, "prefix doubling: tied rows grew %u -> %u", prev_active, hc.active);
+    prev_active = hc.active;
+    if (hc.nbig > cap) return set_error(kErrInternal, "prefix doubling: group list overflow");
+    const uint32_t nbig = hc.nbig;
+    BWT_LAUNCH("dbl_keys", k_dbl_keys, dim3(gr), dim3(256), 0, s, d_sa, ghead, isa.as<uint32_t>(), n, h, rows,
+               key.as<uint32_t>());
+    // groups of more than kDblTile rows, level by level
+    uint32_t nsegs = nbig;
+    Seg *cur = segs_a.as<Seg>(), *next = segs_b.as<Seg>();
+    for (int level = 0; nsegs > 0; ++level) {
+      if (level > 8) return set_error(kErrInternal, "prefix doubling: a group did not split in %d levels", level);
+      BWT_LAUNCH("dbl_seg_tiles", k_dbl_seg_tiles, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s, cur, nsegs,
+                 tiles.as<uint32_t>(), mm.as<uint32_t>());
+      BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tiles.as<uint32_t>(), tiles.as<uint32_t>(), nsegs,
+                              &ctr->total_tiles, scanws.p, scan_workspace_bytes((uint64_t)cap + 1), s));
+      BWT_HIP(hipMemsetAsync(&ctr->nnext, 0, 4, s));
+      BWT_HIP(hipMemsetAsync(counts.p, 0, (size_t)nsegs * 256 * 4, s));
+      const unsigned tile_bound = (unsigned)(rows / kDblPart + nsegs + 1);
+      BWT_LAUNCH("dbl_minmax", k_dbl_minmax, dim3(tile_bound), dim3(kDblPartThreads), 0, s, cur, tiles.as<uint32_t>(),
+                 nsegs, ctr, key.as<uint32_t>(), mm.as<uint32_t>());
+      BWT_LAUNCH("dbl_hist", k_dbl_hist, dim3(tile_bound), dim3(kDblPartThreads), 0, s, cur, tiles.as<uint32_t>(),
+                 nsegs, ctr, key.as<uint32_t>(), mm.as<uint32_t>(), counts.as<uint32_t>());
+      BWT_LAUNCH("dbl_old_labels", k_dbl_old_labels, dim3((unsigned)div_up(nsegs, 256)), dim3(256), 0, s, cur, nsegs,
+                 glabel.as<uint32_t>(), oldl.as<uint32_t>());
+      BWT_LAUNCH("dbl_classify", k_dbl_classify, dim3(nsegs), dim3(256), 0, s, cur, nsegs, mm.as<uint32_t>(),
+                 counts.as<uint32_t>(), pieces.as<uint32_t>(), plabels.as<uint32_t>(), glabel.as<uint32_t>(), next, cap,
+                 ctr);
+      BWT_LAUNCH("dbl_scatter", k_dbl_scatter, dim3(tile_bound), dim3(kDblPartThreads), 0, s, cur,
+                 tiles.as<uint32_t>(), nsegs, ctr, d_sa, key.as<uint32_t>(), mm.as<uint32_t>(), counts.as<uint32_t>(),
+                 pieces.as<uint32_t>(), plabels.as<uint32_t>(), oldl.as<uint32_t>(), alt_sa.as<uint32_t>(),
+                 alt_key.as<uint32_t>(), ghead, isa.as<uint32_t>());
+      BWT_LAUNCH("dbl_copyback", k_dbl_copyback, dim3(tile_bound), dim3(kDblPartThreads), 0, s, cur,
+                 tiles.as<uint32_t>(), nsegs, ctr, mm.as<uint32_t>(), alt_sa.as<uint32_t>(), alt_key.as<uint32_t>(), d_sa,
+                 key.as<uint32_t>());
+      BWT_HIP(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, s));
+      BWT_HIP(hipStreamSynchronize(s));
+      if (hc.nnext > cap) return set_error(kErrInternal, "prefix doubling: piece list overflow");
+      nsegs = hc.nnext;
+      Seg *tmp = cur;
+      cur = next;
+      next = tmp;
+    }
+    if (nbig) BWT_TRY(survey());  // the pieces are groups now: the tiles' heads have changed
+    BWT_LAUNCH("dbl_small", k_dbl_small, dim3(ntiles), dim3(kLeafThreads), 0, s, first_head, last_head, nxt, d_sa,
+               key.as<uint32_t>(), ghead, isa.as<uint32_t>(), glabel.as<uint32_t>());
     BWT_CHECK_LAUNCH();
     h *= 2;
   }
@@ -1563,8 +2276,15 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, leaves_sorted);
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
-    BWT_LAUNCH("sa_unresolved_segs", k_unresolved_segs, dim3(nsegs), dim3(256), 0, s, segs[cur], src, bufA,
-               ghead, depth, n, ctr);
+    uint32_t *shortl = counts;  // the levels are done with their counters: 256 words a segment, 33 used
+    static_assert(kUnresList + 1 <= 256, "a segment's list of short suffixes fits its counters");
+    BWT_HIP(hipMemsetAsync(shortl, 0, (size_t)nsegs * (kUnresList + 1) * 4, s));
+    BWT_LAUNCH("sa_unresolved_segs", k_unresolved_copy, dim3(nsegs * kUnresParts), dim3(256), 0, s, segs[cur], src,
+               bufA, ghead, depth, n, shortl);
+    BWT_LAUNCH("sa_unresolved_segs", k_unresolved_short, dim3((unsigned)div_up(nsegs, 64)), dim3(64), 0, s, segs[cur],
+               bufA, ghead, depth, n, shortl, nsegs, ctr);
+    BWT_LAUNCH("sa_unresolved_segs", k_unresolved_heads, dim3(nsegs * kUnresParts), dim3(256), 0, s, segs[cur], ghead,
+               shortl);
   }
   BWT_CHECK_LAUNCH();
   if (extras && extras->readback && !range && !nsegs) {
@@ -1607,7 +2327,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     if (nleaves_host)
       BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(nleaves_host), dim3(256), 0, s, leaves, leaf_ties,
                  ghead);
-    BWT_TRY(sa_doubling(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
+    BWT_TRY(sa_finish_ties(d_sa, ghead, n, h_ctr.min_depth, bufB, ctr, s));
   }
   return kOk;
 }
@@ -1626,8 +2346,8 @@ int sa_build_settle(SaExtras *extras, hipStream_t s) {
     BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(extras->later.nleaves), dim3(256), 0, s,
                static_cast<const Leaf *>(extras->later.leaves), static_cast<const uint8_t *>(extras->later.leaf_ties),
                extras->later.ghead);
-  BWT_TRY(sa_doubling(extras->later.d_sa, extras->later.ghead, extras->later.n, h_ctr.min_depth,
-                      extras->later.flags, static_cast<Counters *>(extras->later.ctr), s));
+  BWT_TRY(sa_finish_ties(extras->later.d_sa, extras->later.ghead, extras->later.n, h_ctr.min_depth,
+                         extras->later.flags, static_cast<Counters *>(extras->later.ctr), s));
   BWT_HIP(hipStreamSynchronize(s));
   return 1;
 }

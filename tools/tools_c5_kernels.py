@@ -25,4 +25,6 @@ for label, args in (("period 7", (7, 11, 0, 0)), ("period 1000", (1000, 11, 0, 0
     for k, v in sorted(rep.items(), key=lambda kv: -kv[1][1]):
         print(f"   {k:28s} {v[0]:5d} launches {v[1]:9.3f} ms", flush=True)
     print(f"   sum {tot:.2f} ms", flush=True)
+    G.timing_enable(False)
+    print("   certificate (out of range, not a permutation, out of order):", G.sa_certify(t, n, sa), flush=True)
     del sa, t
