@@ -277,26 +277,61 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
     }
   }
   __syncthreads();
-  // greedy merge by one thread into LDS lists, then one reservation per list
-  // and a parallel copy-out (a global atomic per record would serialise)
-  __shared__ uint32_t lstart[256], lsize[256], sidx[256];
+  // Greedy merge of neighbouring small children into leaves.  A run of small children
+  // (between two large ones) is dealt by the thread of its first child; how far a leaf that
+  // starts at child d reaches is found by every thread for its own child at once (a binary
+  // search over prefix sums), so the walk is one hop per leaf, not one step per child.
+  __shared__ uint32_t lstart[256], lsize[256], sidx[256], upto_[257], reach[256], wtot[4];
   __shared__ uint32_t nl, ns, lbase, sbase;
-  if (t == 0) {
-    uint32_t run_start = 0, run_size = 0, l = 0, g = 0;
-    for (int d = 0; d < 256; ++d) {
-      const uint32_t sz = sizes[d];
-      if (!sz) continue;
-      if (sz > kLeafMax) {
-        if (run_size) { lstart[l] = run_start; lsize[l] = run_size; ++l; run_size = 0; }
-        sidx[g++] = (uint32_t)d;
-      } else {
-        if (run_size + sz > kLeafMax) { lstart[l] = run_start; lsize[l] = run_size; ++l; run_size = 0; }
-        if (!run_size) run_start = starts[d];
-        run_size += sz;
-      }
+  constexpr uint32_t kRowsBits = 22;  // 256 small children hold at most 2^20 rows
+  const bool big = c > kLeafMax;
+  {
+    // inclusive scan of (large children so far, rows in small children so far), packed
+    uint32_t pk = big ? (1u << kRowsBits) : c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(pk, off, 64);
+      if (lane >= off) pk += u;
     }
-    if (run_size) { lstart[l] = run_start; lsize[l] = run_size; ++l; }
-    nl = l;
+    if (lane == 63) wtot[wave] = pk;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; ++w) pk += wtot[w];
+    upto_[t + 1] = pk;
+    if (t == 0) {
+      upto_[0] = 0;
+      nl = 0;
+    }
+  }
+  __syncthreads();
+  if (big) {
+    sidx[upto_[t] >> kRowsBits] = t;
+  } else {
+    // the furthest child e such that children t..e are small and hold at most kLeafMax rows
+    const uint32_t from = upto_[t];
+    uint32_t lo = t, hi = 255;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1, upto = upto_[mid + 1];
+      if ((upto >> kRowsBits) == (from >> kRowsBits) && upto - from <= kLeafMax) lo = mid;
+      else hi = mid - 1;
+    }
+    reach[t] = lo;
+  }
+  __syncthreads();
+  if (!big && (t == 0 || sizes[t - 1] > kLeafMax)) {
+    uint32_t d = t;
+    while (d < 256 && sizes[d] <= kLeafMax) {
+      const uint32_t e = reach[d];
+      const uint32_t rows_in = upto_[e + 1] - upto_[d];  // no large child between: the difference is rows alone
+      if (rows_in) {
+        const uint32_t k = atomicAdd(&nl, 1u);
+        lstart[k] = starts[d];
+        lsize[k] = rows_in;
+      }
+      d = e + 1;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const uint32_t l = nl, g = upto_[256] >> kRowsBits;
     ns = g;
     lbase = l ? atomicAdd(&ctr->nleaves, l) : 0u;
     sbase = g ? atomicAdd(&ctr->nnext, g) : 0u;
