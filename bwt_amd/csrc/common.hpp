@@ -169,7 +169,16 @@ constexpr uint32_t kPosPerRecord = 12;
 constexpr uint32_t kPosGuardRecords = 4;
 // largest text whose position + guard still fits 32 bits
 constexpr uint32_t kPosRecordMaxN = 0xFFFFFF00u;
-inline uint64_t pos_record_count(uint32_t n) { return (uint64_t)n / kPosPerRecord + kPosGuardRecords + 2; }
+// Records are kept in groups of eight in the order 0 4 1 5 2 6 3 7: a read of more
+// than 53 bases needs records q and q + 4 (48 bases further), and those are then the
+// two halves of one 128-byte-aligned pair for every second q -- the second half of a
+// pair costs a fifth of a line fetched from elsewhere.
+__host__ __device__ inline uint64_t pos_record_place(uint64_t b) {
+  return (b & ~7ull) | ((b & 3ull) << 1) | ((b >> 2) & 1ull);
+}
+inline uint64_t pos_record_count(uint32_t n) {
+  return ((uint64_t)n / kPosPerRecord + kPosGuardRecords + 2 + 7) / 8 * 8;  // whole groups
+}
 
 // Entries of the list that follows the k-mer table (see index_build_kmer_table):
 // one per suffix shorter than the table's strings, so at most 14.

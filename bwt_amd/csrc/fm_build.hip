@@ -235,7 +235,7 @@ __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, ui
     const int64_t at = first + 16 * k;
     w[k] = (at <= -16 || at >= (int64_t)n) ? 0u : text16(text2, at);
   }
-  reinterpret_cast<uint4 *>(recs)[b * 4 + 3] = make_uint4(w[0], w[1], w[2], w[3]);
+  reinterpret_cast<uint4 *>(recs)[pos_record_place(b) * 4 + 3] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // The position records at d_isa: the inverse of the n+1 rows at d_sa and the

@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t div12(uint32_t p, uint32_t &rem) {
 __device__ __forceinline__ uint64_t isa_slot(uint32_t p) {
   uint32_t o;
   const uint32_t b = div12(p, o);
-  return ((uint64_t)b + kPosGuardRecords) * 16u + o;
+  return pos_record_place((uint64_t)b + kPosGuardRecords) * 16u + o;
 }
 
 __device__ __forceinline__ uint32_t isa_at(const IndexView &v, uint32_t p) { return v.isa[isa_slot(p)]; }

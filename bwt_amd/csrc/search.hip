@@ -212,9 +212,9 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     for (int g = (int)((rem - 1) / 48u); g >= 0 && jbad < 0 && !before_text; --g) {
       if (48u * g + 48u <= jmin) break;
       uint32_t o;
-      const uint32_t b = div12((pos + 48u) - (rem - 48u * g), o);  // guard records included
-      const uint4 tx = reinterpret_cast<const uint4 *>(v.isa)[(uint64_t)b * 4u + 3u];
-      if (g == 0 && jmin == 0) row_all = v.isa[(uint64_t)b * 16u + o];
+      const uint64_t b = pos_record_place(div12((pos + 48u) - (rem - 48u * g), o));  // guard records included
+      const uint4 tx = reinterpret_cast<const uint4 *>(v.isa)[b * 4u + 3u];
+      if (g == 0 && jmin == 0) row_all = v.isa[b * 16u + o];
       if (COUNT) ++n_txt;
       for (int wl = 2; wl >= 0 && jbad < 0; --wl) {
         const uint32_t w = 3u * g + wl;
