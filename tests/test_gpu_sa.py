@@ -93,11 +93,18 @@ def test_sa_tandem_repeat(oracle, gpu, n, period):
     assert st[2] > 0 and st[3] > 0, st  # unresolved rows went through doubling rounds
 
 
-def test_sa_repeat_with_point_mutations(oracle, gpu):
+@pytest.mark.parametrize("form", ["groups", "lsd"])
+def test_sa_repeat_with_point_mutations(oracle, gpu, form, monkeypatch):
+    """form lsd: the rounds as one radix sort of (group, key) each, kept beside the
+    group-by-group rounds for comparison (BWT_MI355X_DOUBLING)"""
+    if form == "lsd":
+        monkeypatch.setenv("BWT_MI355X_DOUBLING", "lsd")
     n = 500000
     text = oracle.gen_tandem(n, 1000, 11, mut_every=997, mut_seed=3)
     want = oracle.sa_doubling(text, n)
     _check_sa(oracle, gpu, text, n, want)
+    text = oracle.gen_tandem(3_000_000, 31, 5, mut_every=40000, mut_seed=9)  # a few groups of 10^5 rows
+    _check_sa(oracle, gpu, text, 3_000_000, oracle.sa_doubling(text, 3_000_000))
 
 
 @pytest.mark.parametrize("bases", ["A", "T", "AC", "T" * 34, "ACGT" * 50, "A" * 5000, "T" * 5000 + "A" * 5000,
