@@ -31,6 +31,8 @@ constexpr int kPartThreads = 256;                      // histogram workgroup
 constexpr int kScatThreads = 512;                      // scatter workgroup
 constexpr int kPartItems = 16;                         // suffixes per scatter thread
 constexpr int kPartTile = kScatThreads * kPartItems;   // 8192 suffixes per tile: 32-element runs per bucket
+constexpr int kScat1Threads = 1024;                    // scatter of the levels after the first: the same tile, more waves
+constexpr int kScat1Items = kPartTile / kScat1Threads;
 constexpr int kHistItems = kPartTile / kPartThreads;
 constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
 constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
@@ -427,7 +429,7 @@ k_restrict_level0(const uint32_t *__restrict__ counts /* [8][256], one row per e
 // it, and the word is passed on; fresh keys are gathered from the text only when
 // the stored words have run out of bases (see carried_word).  Level 0 has a
 // kernel of its own (k_part_scatter0).
-__global__ void __launch_bounds__(kScatThreads)
+__global__ void __launch_bounds__(kScat1Threads)
 k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
                const uint32_t *__restrict__ srckey, uint32_t *__restrict__ dst,
                uint32_t *__restrict__ dstkey, const Seg *__restrict__ segs,
@@ -447,10 +449,10 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   if (!locate_tile(segs, tile_first, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
-  uint32_t id[kPartItems], key[kPartItems];
+  uint32_t id[kScat1Items], key[kScat1Items];
 #pragma unroll
-  for (int i = 0; i < kPartItems; ++i) {
-    const uint32_t j = (uint32_t)i * kScatThreads + t;
+  for (int i = 0; i < kScat1Items; ++i) {
+    const uint32_t j = (uint32_t)i * kScat1Threads + t;
     if (j < count) {
       id[i] = src[row0 + j];
       const uint32_t old = srckey[row0 + j];
@@ -486,8 +488,8 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < kPartItems; ++i) {
-    if ((uint32_t)i * kScatThreads + t < count) {
+  for (int i = 0; i < kScat1Items; ++i) {
+    if ((uint32_t)i * kScat1Threads + t < count) {
       const uint32_t d = key[i] >> 24;
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
@@ -497,7 +499,7 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   if (t < 256) gbase[t] = claimed;
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
-  for (uint32_t j = t; j < placed; j += kScatThreads) {
+  for (uint32_t j = t; j < placed; j += kScat1Threads) {
     const uint32_t k = kv[j];
     const uint32_t pos = gbase[k >> 24] + (j - lstart[k >> 24]);
     dst[pos] = ids[j];
@@ -588,7 +590,7 @@ k_part_hist0(const uint32_t *__restrict__ tb, uint32_t n, const Counters *__rest
 // A suffix that goes on to level 1 carries bases 4..18 (its digit is implied by
 // its bucket), one that ends in a level-0 leaf bases 0..14; both with the base
 // before it.  Positions whose digit lies outside [dlo, dhi) are dropped.
-__global__ void __launch_bounds__(kScatThreads)
+__global__ void __launch_bounds__(kScat1Threads)
 k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restrict__ dst,
                 uint32_t *__restrict__ dstkey, const Counters *__restrict__ ctr,
                 uint32_t *__restrict__ cursors /* [8][256]: one row per eighth of the tiles */,
@@ -610,9 +612,11 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
   const uint32_t row0 = tile * (uint32_t)kPartTile;
   const uint32_t count = n - row0 < (uint32_t)kPartTile ? n - row0 : (uint32_t)kPartTile;
   __syncthreads();
-  // 16 consecutive positions per thread: their word, the base before it, two words of lookahead
-  const uint64_t w = ((uint64_t)row0 >> 4) + t;
-  const uint32_t p0 = 16u * t;
+  // eight consecutive positions per thread, one half of a text word: the word, the base before
+  // it, two words of lookahead
+  const uint32_t h8 = 8u * (t & 1u);
+  const uint64_t w = ((uint64_t)row0 >> 4) + (t >> 1);
+  const uint32_t p0 = 8u * t;
   uint32_t w0 = 0, w1 = 0, w2 = 0, prev = 0;
   if (p0 < count) {  // the text is padded by a few words only
     w0 = tb[w];
@@ -622,9 +626,9 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
   }
   uint32_t kept = 0;  // bit q: position p0 + q is this shard's
 #pragma unroll
-  for (uint32_t q = 0; q < 16; ++q) {
+  for (uint32_t q = 0; q < 8; ++q) {
     if (p0 + q < count) {
-      const uint32_t d = window16(w0, w1, w2, q) >> 24;
+      const uint32_t d = window16(w0, w1, w2, h8 + q) >> 24;
       if (d >= dlo && d < dhi) {
         kept |= 1u << q;
         atomicAdd(&hist[d], 1u);
@@ -652,13 +656,14 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
   }
   __syncthreads();
 #pragma unroll
-  for (uint32_t q = 0; q < 16; ++q) {
+  for (uint32_t q = 0; q < 8; ++q) {
     if ((kept >> q) & 1u) {
-      const uint32_t k32 = window16(w0, w1, w2, q);
+      const uint32_t o = h8 + q;  // place in the word
+      const uint32_t k32 = window16(w0, w1, w2, o);
       const uint32_t d = k32 >> 24;
       const bool leaf = (lmask[d >> 5] >> (d & 31u)) & 1u;
-      const uint32_t key = leaf ? k32 : window16(w0, w1, w2, q + 4);
-      const uint32_t bw = q ? (w0 >> (32u - 2u * q)) & 3u : prev;  // the base before position p0 + q
+      const uint32_t key = leaf ? k32 : window16(w0, w1, w2, o + 4);
+      const uint32_t bw = o ? (w0 >> (32u - 2u * o)) & 3u : prev;  // the base before position p0 + q
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = (d << 24) | (p0 + q);
       kv[p] = (key & ~3u) | ((row0 + p0 + q) ? bw : 0u);
@@ -667,7 +672,7 @@ k_part_scatter0(const uint32_t *__restrict__ tb, uint32_t n, uint32_t *__restric
   if (t < 256) gbase[t] = claimed;  // the claim was in flight while the tile was put in order
   __syncthreads();
   const uint32_t placed = lstart[255] + hist[255];
-  for (uint32_t j = t; j < placed; j += kScatThreads) {
+  for (uint32_t j = t; j < placed; j += kScat1Threads) {
     const uint32_t id = ids[j];
     const uint32_t d = id >> 24;
     const uint32_t pos = gbase[d] + (j - lstart[d]);
@@ -2260,12 +2265,12 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
                L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0);
     if (src_id == kSrcImplicit) {
-      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScatThreads), 0, s, tb, n, dst,
+      BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, n, dst,
                  dstkey, ctr, counts, leafmask, dlo, dhi);
       reach = kDigitBases + kLeafKeyBases;  // suffixes that go on carry bases 4..18
     } else {
       BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter,
-                 dim3(tile_bound), dim3(kScatThreads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
+                 dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
                  depth, ctr, counts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
       if (gather_all) reach = depth + kLeafKeyBases;
     }
