@@ -117,8 +117,8 @@ __global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows, uin
 // position -- bin b owns positions [b << shift, (b+1) << shift), so its pairs
 // fill exactly that range of the pair buffer and no counting pass is needed --
 // then the bins are emptied in order.
-constexpr int kIsaThreads = 512;
-constexpr int kIsaItems = 16;
+constexpr int kIsaThreads = 1024;  // the 64 KB of staging allow two workgroups per CU: 1024 threads fill every wave slot
+constexpr int kIsaItems = 8;
 constexpr int kIsaTile = kIsaThreads * kIsaItems;  // 8192 pairs: 32-pair (256-byte) runs per bin
 
 __global__ void k_isa_cursors1(uint32_t shift, unsigned long long *__restrict__ cursors) {

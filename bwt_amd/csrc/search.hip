@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
          uint64_t stride, uint64_t R, uint32_t m, uint32_t *__restrict__ d_sp,
          uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
-         unsigned long long *__restrict__ counters, uint64_t wstride, uint64_t rstride) {
+         unsigned long long *__restrict__ counters, uint64_t wstride, uint64_t rstride, uint32_t rounds) {
   // !FUSED: word w of read r is packed[w * wstride + r * rstride] -- (R, 1) for the
   // word-major form k_pack_reads writes, (1, words per read) for reads packed
   // one after the other (bwtgpu_search_packed)
@@ -110,26 +110,36 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   const uint32_t *lw = nullptr;  // FUSED: word w of this lane's read at lw[w * blockDim.x]
   const uint32_t nt = blockDim.x;  // reads per workgroup: 256, fewer for long reads in the fused form
   if (FUSED) {
+    // The bytes of the workgroup's reads go through LDS in `rounds` parts (nt / rounds reads
+    // each, all threads copying, the part's own threads packing), so that the byte area is
+    // a fraction of the reads: LDS per workgroup decides how many waves a CU holds.
     const uint32_t words = (m + 15) / 16;
     uint32_t *wbase = reinterpret_cast<uint32_t *>(lds);  // [words][nt], then the staged bytes
     uint8_t *bytes = lds + (size_t)words * nt * 4;
-    const uint8_t *src = pats + r0 * stride;
-    const uint64_t last = R - 1 < r0 + nt - 1 ? R - 1 : r0 + nt - 1;
-    const uint32_t span = (uint32_t)((last - r0) * stride + m);
-    const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
-    const uint8_t *asrc = src - mis;  // see k_pack_reads
-    const uint32_t total = mis + span, vecs = total / 16;
-    for (uint32_t i = t; i < vecs; i += nt)
-      reinterpret_cast<u32x4 *>(bytes)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(asrc) + i);
-    for (uint32_t i = vecs * 16 + t; i < total; i += nt) bytes[i] = asrc[i];
-    __syncthreads();
-    if (r < R) {
-      const uint8_t *mine = bytes + mis + (uint32_t)(t * stride);
-      for (uint32_t w = 0; w < words; ++w) {
-        uint32_t acc = 0;
-        const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
-        for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
-        wbase[w * nt + t] = acc;
+    const uint32_t part = nt / rounds;
+    for (uint32_t q = 0; q < rounds; ++q) {
+      const uint64_t p0 = r0 + (uint64_t)q * part;  // first read of the part
+      if (q) __syncthreads();                       // the part before has been packed
+      if (p0 < R) {
+        const uint8_t *src = pats + p0 * stride;
+        const uint64_t last = R - 1 < p0 + part - 1 ? R - 1 : p0 + part - 1;
+        const uint32_t span = (uint32_t)((last - p0) * stride + m);
+        const uint32_t mis = (uint32_t)((uintptr_t)src & 15u);
+        const uint8_t *asrc = src - mis;  // see k_pack_reads
+        const uint32_t total = mis + span, vecs = total / 16;
+        for (uint32_t i = t; i < vecs; i += nt)
+          reinterpret_cast<u32x4 *>(bytes)[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(asrc) + i);
+        for (uint32_t i = vecs * 16 + t; i < total; i += nt) bytes[i] = asrc[i];
+        __syncthreads();
+        if (r < R && t / part == q) {
+          const uint8_t *mine = bytes + mis + (uint32_t)((t - q * part) * stride);
+          for (uint32_t w = 0; w < words; ++w) {
+            uint32_t acc = 0;
+            const uint32_t kmax = m - 16 * w < 16 ? m - 16 * w : 16;
+            for (uint32_t k = 0; k < kmax; ++k) acc |= (uint32_t)(mine[16 * w + k] & 3u) << (2 * k);
+            wbase[w * nt + t] = acc;
+          }
+        }
       }
     }
     lw = wbase + t;  // only this lane reads its own words: no barrier needed
@@ -522,13 +532,28 @@ constexpr uint32_t kFusedLdsBytes = 40 * 1024;
 // Reads per workgroup (256, 128 or 64) with which the bytes and packed words of
 // a workgroup's reads fit kFusedLdsBytes, so that k_search packs them itself and
 // the packed-read workspace is never touched; 0 when even 64 reads do not fit.
-static uint32_t fused_group_reads(uint32_t m, uint64_t stride, uint64_t R, uint64_t *lds_bytes) {
+// *rounds: in how many parts the bytes pass through LDS.  One part while the workgroup then
+// needs no more than kFusedLdsFull bytes (eight workgroups of 256 to a CU: every wave slot
+// taken); else as many parts (up to 8) as it takes to get there, or at least under the limit.
+constexpr uint32_t kFusedLdsFull = 20 * 1024;
+static uint32_t fused_group_reads(uint32_t m, uint64_t stride, uint64_t R, uint64_t *lds_bytes, uint32_t *rounds) {
   for (uint32_t nt = 256; nt >= 64; nt /= 2) {
-    const uint64_t bytes = align_up((uint64_t)(nt - 1) * stride + m + 16, 16);
-    const uint64_t fused_lds = bytes + (uint64_t)((m + 15) / 16) * nt * 4;
-    if (fused_lds > kFusedLdsBytes) continue;
     if (div_up(R, nt) > 0x7FFFFFFFull) return 0;
-    *lds_bytes = fused_lds;
+    const uint64_t wordbytes = (uint64_t)((m + 15) / 16) * nt * 4;
+    const uint64_t target = (uint64_t)kFusedLdsFull * nt / 256;
+    uint32_t best = 0;
+    uint64_t best_lds = 0;
+    for (uint32_t q = 1; q <= 8 && q <= nt / 8; q *= 2) {
+      const uint64_t bytes = align_up((uint64_t)(nt / q - 1) * stride + m + 16, 16);
+      const uint64_t fused_lds = bytes + wordbytes;
+      if (fused_lds > kFusedLdsBytes) continue;
+      best = q;
+      best_lds = fused_lds;
+      if (fused_lds <= target) break;
+    }
+    if (!best) continue;
+    *lds_bytes = best_lds;
+    *rounds = best;
     return nt;
   }
   return 0;
@@ -542,7 +567,8 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   if (R == 0) return kOk;
   if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
   uint64_t fused_lds = 0;
-  const uint32_t fused_nt = d_counters ? 0u : fused_group_reads(m, stride, R, &fused_lds);
+  uint32_t fused_rounds = 1;
+  const uint32_t fused_nt = d_counters ? 0u : fused_group_reads(m, stride, R, &fused_lds, &fused_rounds);
   if (!fused_nt && ws_bytes < bwtgpu_search_workspace_bytes(R, m))
     return set_error(kErrWorkspace, "search workspace %zu < %zu bytes", ws_bytes,
                      bwtgpu_search_workspace_bytes(R, m));
@@ -561,10 +587,10 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
     if (ix->d_isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, fused_rounds);
     else
       BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, fused_rounds);
     BWT_CHECK_LAUNCH();
     return kOk;
   }
@@ -575,16 +601,16 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   if (d_counters) {
     if (ix->d_isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
   } else if (ix->d_isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
-               d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+               d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
   } else {
     BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R,
-               m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1);
+               m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
   }
   BWT_CHECK_LAUNCH();
   return kOk;
@@ -613,11 +639,11 @@ int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32
   const uint64_t words = (m + 15) / 16;
   if (ix->d_isa)
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, d_words, (const uint8_t *)nullptr,
-               (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr, (uint64_t)1, words);
+               (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
   else
     BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, d_words,
                (const uint8_t *)nullptr, (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr,
-               (uint64_t)1, words);
+               (uint64_t)1, words, 1u);
   BWT_CHECK_LAUNCH();
   return kOk;
 }
@@ -635,7 +661,8 @@ int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
   // reads short enough to be packed inside the kernel use no scratch at all;
   // longer ones must fit their packed words into the static array
   uint64_t lds = 0;
-  if (m && m <= 65535 && R && R <= (1ull << 40) && !fused_group_reads(m, stride, R, &lds) &&
+  uint32_t rounds = 1;
+  if (m && m <= 65535 && R && R <= (1ull << 40) && !fused_group_reads(m, stride, R, &lds, &rounds) &&
       bwtgpu_search_workspace_bytes(R, m) > kStaticScratchBytes)
     return set_error(kErrArg,
                      "%llu reads of %u bases need %zu bytes of scratch, bwtgpu_search_static has %zu: "

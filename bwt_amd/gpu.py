@@ -143,6 +143,9 @@ class GpuIndex:
         """bwtgpu_search_static: the same search with the library's own static
         scratch in place of a workspace argument."""
         stride = m if stride is None else stride
+        need = (R - 1) * stride + m if R else 0
+        if d_pats.numel() < need:
+            raise ValueError(f"pattern buffer holds {d_pats.numel()} bytes, needs {need}")
         sp = torch.empty(R, dtype=torch.int32, device="cuda")
         ep = torch.empty(R, dtype=torch.int32, device="cuda")
         lr = torch.empty(R, dtype=torch.int32, device="cuda") if want_locrow else None
@@ -170,6 +173,9 @@ class GpuIndex:
         bwtgpu_search_profile) and the bytes they add up to."""
         lib = _lib.load()
         stride = m if stride is None else stride
+        need = (R - 1) * stride + m if R else 0
+        if d_pats.numel() < need:
+            raise ValueError(f"pattern buffer holds {d_pats.numel()} bytes, needs {need}")
         sp = torch.empty(R, dtype=torch.int32, device="cuda")
         ep = torch.empty(R, dtype=torch.int32, device="cuda")
         ws = torch.empty(int(lib.bwtgpu_search_workspace_bytes(R, m)) + 256, dtype=torch.uint8, device="cuda")

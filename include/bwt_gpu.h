@@ -251,7 +251,7 @@ int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32
  * or by the first call on that device).  The call itself allocates nothing,
  * which includes the search-only arrays of bwtgpu_index_prepare_search: it
  * uses them when they are there and searches on the rank blocks when not.
- * Reads short enough to be packed inside the search kernel (up to about 500
+ * Reads short enough to be packed inside the search kernel (up to about 1700
  * bases at stride = m) use no scratch and any R is accepted; for longer reads
  * ((m+15)/16) * 4 * R + 512 bytes must fit the 16 MiB, else the call fails with
  * -2 and a message that says so.  All calls on one GPU share that GPU's array:

@@ -29,8 +29,9 @@ def test_static_search_equals_search_twice_in_a_row(oracle, gpu, built_from_text
     text = oracle.gen_genome(n, synth.GENOME_SEED)
     fo = oracle.make_fmi(text, n)
     ix = gpu.build_index(text, n) if built_from_text else gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)
-    # m = 600: the packed reads go through the scratch; m = 50: packed inside the kernel
-    for m, R_big, R_small in ((600, 3000, 701), (50, 20000, 4099), (1000, 513, 64)):
+    # m = 2000, 3000: the packed reads go through the scratch; m = 50, 600: packed inside the kernel
+    # (600-base reads in parts: the bytes of 8 reads at a time pass through LDS)
+    for m, R_big, R_small in ((2000, 3000, 701), (50, 20000, 4099), (3000, 513, 64), (600, 3000, 701)):
         big = _reads(oracle, text, n, R_big, m, synth.READS_SEED + m)
         small = _reads(oracle, text, n, R_small, m, synth.READS_SEED + m + 1)
         want_big = ix.search(big, m, R_big, want_locrow=True)
@@ -52,8 +53,9 @@ def test_static_search_refuses_batches_beyond_its_scratch(oracle, gpu):
     n = 50_000
     text = oracle.gen_genome(n, synth.GENOME_SEED)
     ix = gpu.build_index(text, n)
-    m, R = 600, 200_000  # 38 words a read: 30.4 MB of packed reads > 16 MiB
-    d = torch.zeros(R * m + 64, dtype=torch.uint8, device="cuda")
+    m, R = 3000, 30_000  # 188 words a read: 22.6 MB of packed reads > 16 MiB
+    m2, R2 = 40, 3_000_000
+    d = torch.zeros(max(R * m, R2 * m2) + 64, dtype=torch.uint8, device="cuda")
     with pytest.raises(gpu.BwtGpuError, match="bytes of scratch"):
         ix.search_static(d, m, R)
     # the same reads in two halves... still too many; a tenth fits
@@ -61,7 +63,6 @@ def test_static_search_refuses_batches_beyond_its_scratch(oracle, gpu):
     sp2, ep2 = ix.search(d, m, R // 10)
     _same(gpu, (sp, ep), (sp2, ep2))
     # short reads are not limited: they never touch the scratch
-    m2, R2 = 40, 3_000_000
     sp, ep = ix.search_static(d, m2, R2)
     sp2, ep2 = ix.search(d, m2, R2)
     _same(gpu, (sp, ep), (sp2, ep2))
