@@ -1401,7 +1401,7 @@ constexpr uint32_t kDblTile = 2048;           // rows per tile; a group of up to
 constexpr uint32_t kDblChunk = 4096;          // rows a partition workgroup holds at a time (256 threads x 16)
 constexpr uint32_t kDblChunks = 4;            // ... and chunks it takes one after the other: one claim of room for all
 constexpr uint32_t kDblPart = kDblChunk * kDblChunks;
-constexpr uint32_t kDblPartThreads = 256;
+constexpr uint32_t kDblPartThreads = 512;  // two waves a SIMD more than 256 for the same LDS; the 256 bins are the first 256 threads'
 constexpr uint32_t kDblItems = kDblChunk / kDblPartThreads;
 constexpr uint32_t kDblNone = 0xFFFFFFFFu;
 
@@ -1647,7 +1647,7 @@ k_dbl_hist(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first
            uint32_t *__restrict__ counts) {
   __shared__ TileInfo ti;
   __shared__ uint32_t hist[256];
-  hist[threadIdx.x] = 0;
+  if (threadIdx.x < 256) hist[threadIdx.x] = 0;
   if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t lo = mm[2 * ti.seg], hi = mm[2 * ti.seg + 1];
   if (lo >= hi) return;  // one key: the group stays as it is this round
@@ -1662,8 +1662,10 @@ k_dbl_hist(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first
     }
   }
   __syncthreads();
-  const uint32_t c = hist[threadIdx.x];
-  if (c) atomicAdd(&counts[(uint64_t)ti.seg * 256 + threadIdx.x], c);
+  if (threadIdx.x < 256) {
+    const uint32_t c = hist[threadIdx.x];
+    if (c) atomicAdd(&counts[(uint64_t)ti.seg * 256 + threadIdx.x], c);
+  }
 }
 
 // counts -> first rows of the 256 pieces (cursors for the scatter, and a copy that
@@ -1720,7 +1722,8 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
   __shared__ uint32_t ids[kDblChunk], kv[kDblChunk];
   __shared__ uint8_t dig[kDblChunk];
   const uint32_t t = threadIdx.x;
-  hist[t] = 0;
+  const bool bin = t < 256;  // the thread that looks after digit t
+  if (bin) hist[t] = 0;
   if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
   const uint32_t lo = mm[2 * ti.seg], hi = mm[2 * ti.seg + 1];
   if (lo >= hi) return;
@@ -1738,7 +1741,7 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
     }
   }
   __syncthreads();
-  {
+  if (bin) {
     const uint32_t c = hist[t];
     gbase[t] = c ? atomicAdd(&cursors[(uint64_t)ti.seg * 256 + t], c) : 0u;
     pstart[t] = piece_start[(uint64_t)ti.seg * 256 + t];
@@ -1747,7 +1750,7 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
   for (uint32_t c0 = 0; c0 < count; c0 += kDblChunk) {
     const uint32_t cc = count - c0 < kDblChunk ? count - c0 : kDblChunk;
     __syncthreads();  // the chunk before has been written out; the claims have landed
-    hist[t] = 0;
+    if (bin) hist[t] = 0;
     __syncthreads();
     uint32_t id[kDblItems], kk[kDblItems], dd[kDblItems], place[kDblItems];
 #pragma unroll
@@ -1762,17 +1765,19 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
     for (uint32_t i = 0; i < kDblItems; ++i)
       place[i] = dbl_count(hist, dd[i], i * kDblPartThreads + t < cc, lane);  // its place among the chunk's rows of that digit
     __syncthreads();
-    const uint32_t c = hist[t];
+    const uint32_t c = bin ? hist[t] : 0u;
     uint32_t v = c;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t u = __shfl_up(v, off, 64);
       if (lane >= off) v += u;
     }
-    if (lane == 63) wsum[wave] = v;
+    if (bin && lane == 63) wsum[wave] = v;
     __syncthreads();
-    uint32_t pre = 0;
-    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
-    lstart[t] = pre + v - c;
+    if (bin) {
+      uint32_t pre = 0;
+      for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+      lstart[t] = pre + v - c;
+    }
     __syncthreads();
 #pragma unroll
     for (uint32_t i = 0; i < kDblItems; ++i) {
@@ -1797,7 +1802,7 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
       }
     }
     __syncthreads();
-    gbase[t] += c;  // the chunk's share of the claim is used up
+    if (bin) gbase[t] += c;  // the chunk's share of the claim is used up
   }
 }
 
