@@ -63,6 +63,10 @@ SIGNATURES = {
     "bwtgpu_search_workspace_bytes": (sz, [u64, u32]),
     "bwtgpu_search": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
     "bwtgpu_search_packed": (C.c_int, [vp, vp, u32, u64, vp, vp, vp, vp]),
+    "bwtgpu_search_locate_workspace_bytes": (sz, [u64, u32]),
+    "bwtgpu_search_locate": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp, sz, vp]),
+    "bwtgpu_search_locate_packed_workspace_bytes": (sz, [u64]),
+    "bwtgpu_search_locate_packed": (C.c_int, [vp, vp, u32, u64, vp, vp, vp, vp, sz, vp]),
     "bwtgpu_pack_reads_host": (C.c_int, [vp, u32, u64, u64, vp]),
     "bwtgpu_search_packed_host": (C.c_int, [vp, vp, u32, u64, vp, vp, vp, vp]),
     "bwtgpu_search_static": (C.c_int, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),

@@ -250,6 +250,10 @@ int static_scratch_setup(int device, void **out = nullptr);
 
 // hoststream.hip: host batches through pinned staging, packed on the way
 bool host_batch_prefers_packing(uint32_t m, uint64_t stride, uint64_t R);
+// search.hip: the packed-read search with both optional outputs, rows (d_locrow) and
+// positions (d_pos; only an index with position records, ix->d_isa, can fill those)
+int search_packed_dev(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,
+                      uint32_t *d_ep, uint32_t *d_locrow, uint32_t *d_pos, hipStream_t s);
 int search_host_streamed(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m, uint64_t stride, uint64_t R,
                          uint32_t *h_sp, uint32_t *h_ep, uint32_t *h_locrow, uint32_t *h_pos);
 void pinned_release_idle();

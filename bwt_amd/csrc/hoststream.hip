@@ -261,10 +261,15 @@ static int search_stream(const bwtgpu_index *ix, const uint8_t *h_pats, uint64_t
     }
     BWT_HIP(hipMemcpyAsync(s.d_in, s.h_in, c * words * 4, hipMemcpyHostToDevice, s.stream));
     uint32_t *d = s.d_out;
-    BWT_TRY(bwtgpu_search_packed(ix, s.d_in, m, c, d, d + chunk, want_row ? d + 2 * chunk : nullptr, s.stream));
-    if (h_pos)
-      BWT_TRY(bwtgpu_locate_rows(ix, d + 2 * chunk, c, d + 3 * chunk, nullptr, s.d_lws, bwtgpu_locate_workspace_bytes(),
-                                 s.stream));
+    if (h_pos && ix->d_isa) {  // the search kernel writes the positions itself
+      BWT_TRY(search_packed_dev(ix, s.d_in, m, c, d, d + chunk, h_locrow ? d + 2 * chunk : nullptr, d + 3 * chunk,
+                                s.stream));
+    } else {
+      BWT_TRY(bwtgpu_search_packed(ix, s.d_in, m, c, d, d + chunk, want_row ? d + 2 * chunk : nullptr, s.stream));
+      if (h_pos)
+        BWT_TRY(bwtgpu_locate_rows(ix, d + 2 * chunk, c, d + 3 * chunk, nullptr, s.d_lws,
+                                   bwtgpu_locate_workspace_bytes(), s.stream));
+    }
     if (h_sp) BWT_HIP(hipMemcpyAsync(s.h_out, d, c * 4, hipMemcpyDeviceToHost, s.stream));
     if (h_ep) BWT_HIP(hipMemcpyAsync(s.h_out + chunk, d + chunk, c * 4, hipMemcpyDeviceToHost, s.stream));
     if (h_locrow) BWT_HIP(hipMemcpyAsync(s.h_out + 2 * chunk, d + 2 * chunk, c * 4, hipMemcpyDeviceToHost, s.stream));

@@ -98,7 +98,7 @@ template <bool VERIFY, bool COUNT, bool FUSED>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
          uint64_t stride, uint64_t R, uint32_t m, uint32_t *__restrict__ d_sp,
-         uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow,
+         uint32_t *__restrict__ d_ep, uint32_t *__restrict__ d_locrow, uint32_t *__restrict__ d_pos,
          unsigned long long *__restrict__ counters, uint64_t wstride, uint64_t rstride, uint32_t rounds) {
   // !FUSED: word w of read r is packed[w * wstride + r * rstride] -- (R, 1) for the
   // word-major form k_pack_reads writes, (1, words per read) for reads packed
@@ -184,6 +184,10 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     i = (int)m - 2;
   }
   bool early = false;
+  // d_pos: the text position of row sp, when the search came by it anyway -- the table's
+  // position word while no step has moved sp, the place the read was compared at
+  uint32_t known_pos = 0xFFFFFFFFu;
+  if (VERIFY && i < 0) known_pos = table_pos;
   const uint4 *sym = reinterpret_cast<const uint4 *>(v.sym);
   for (; i >= 0; --i) {
     if ((i & 15) == 15) {
@@ -252,6 +256,7 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     if (jbad < 0) {
       sp = row_all;
       ep = sp + 1;
+      known_pos = pos - rem;  // row_all = ISA[pos - rem]
     } else {
       const uint32_t k = rem - 1 - (uint32_t)jbad;  // bases that did match
       const uint32_t row = k ? isa_at(v, pos - k) : sp;
@@ -273,6 +278,11 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
   __builtin_nontemporal_store(sp, d_sp + r);
   __builtin_nontemporal_store(ep, d_ep + r);
   if (d_locrow) __builtin_nontemporal_store(early ? 0xFFFFFFFFu : (sp > v.n ? 0xFFFFFFFEu : sp), d_locrow + r);
+  if (VERIFY && d_pos) {  // locate() of the read (seqindex.c:258-277): SA[sp] unless the interval emptied early
+    uint32_t p = 0xFFFFFFFFu;
+    if (!early && sp <= v.n) p = known_pos != 0xFFFFFFFFu ? known_pos : v.sa[sp];
+    __builtin_nontemporal_store(p, d_pos + r);
+  }
   }
   if (COUNT) {
     if (r >= R) n_pat = 0;
@@ -559,13 +569,16 @@ static uint32_t fused_group_reads(uint32_t m, uint64_t stride, uint64_t R, uint6
   return 0;
 }
 
+// d_pos (optional): the position locate() returns for the read, written by the search
+// kernel itself; only for an index that keeps its position records (ix->d_isa).
 static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
-                       uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
-                       size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
+                       uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, uint32_t *d_pos,
+                       void *d_ws, size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
   if (!ix || !d_pats || !d_sp || !d_ep || !d_ws) return set_error(kErrArg, "null argument");
   if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
   if (R == 0) return kOk;
   if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
+  if (d_pos && !ix->d_isa) return set_error(kErrArg, "positions from the search kernel need the position records");
   uint64_t fused_lds = 0;
   uint32_t fused_rounds = 1;
   const uint32_t fused_nt = d_counters ? 0u : fused_group_reads(m, stride, R, &fused_lds, &fused_rounds);
@@ -587,10 +600,10 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
     if (ix->d_isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, fused_rounds);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, fused_rounds);
     else
       BWT_LAUNCH("fm_search", (k_search<false, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
-                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, fused_rounds);
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, fused_rounds);
     BWT_CHECK_LAUNCH();
     return kOk;
   }
@@ -601,16 +614,16 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   if (d_counters) {
     if (ix->d_isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
-                 stride, R, m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
+                 stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
   } else if (ix->d_isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
-               d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
+               d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
   } else {
     BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R,
-               m, d_sp, d_ep, d_locrow, d_counters, R, (uint64_t)1, 1u);
+               m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
   }
   BWT_CHECK_LAUNCH();
   return kOk;
@@ -620,18 +633,12 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uin
                   uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                   size_t ws_bytes, void *stream) {
   if (ix) BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
-  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_ws, ws_bytes, nullptr,
+  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_ws, ws_bytes, nullptr,
                      (hipStream_t)stream);
 }
 
-int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,
-                         uint32_t *d_ep, uint32_t *d_locrow, void *stream) {
-  hipStream_t s = (hipStream_t)stream;
-  if (!ix || !d_words || !d_sp || !d_ep) return set_error(kErrArg, "null argument");
-  if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
-  if (R == 0) return kOk;
-  if (div_up(R, 256) > 0x7FFFFFFFull) return set_error(kErrArg, "too many reads for one launch");
-  BWT_TRY(index_ready_for_search(ix, s));
+static int search_packed_impl(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R,
+                              uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, uint32_t *d_pos, hipStream_t s) {
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   const IndexView v = view_of(ix);
@@ -639,13 +646,87 @@ int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32
   const uint64_t words = (m + 15) / 16;
   if (ix->d_isa)
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, d_words, (const uint8_t *)nullptr,
-               (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
+               (uint64_t)0, R, m, d_sp, d_ep, d_locrow, d_pos, (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
   else
     BWT_LAUNCH("fm_search", (k_search<false, false, false>), grid, block, 0, s, v, C, d_words,
-               (const uint8_t *)nullptr, (uint64_t)0, R, m, d_sp, d_ep, d_locrow, (unsigned long long *)nullptr,
-               (uint64_t)1, words, 1u);
+               (const uint8_t *)nullptr, (uint64_t)0, R, m, d_sp, d_ep, d_locrow, d_pos,
+               (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
   BWT_CHECK_LAUNCH();
   return kOk;
+}
+
+static int packed_args_ok(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R,
+                          const uint32_t *d_sp, const uint32_t *d_ep) {
+  if (!ix || !d_words || !d_sp || !d_ep) return set_error(kErrArg, "null argument");
+  if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
+  if (div_up(R, 256) > 0x7FFFFFFFull) return set_error(kErrArg, "too many reads for one launch");
+  return kOk;
+}
+
+int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,
+                         uint32_t *d_ep, uint32_t *d_locrow, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  BWT_TRY(packed_args_ok(ix, d_words, m, R, d_sp, d_ep));
+  if (R == 0) return kOk;
+  BWT_TRY(index_ready_for_search(ix, s));
+  return search_packed_impl(ix, d_words, m, R, d_sp, d_ep, d_locrow, nullptr, s);
+}
+
+// Room for the rows of a batch (an index without position records locates in a second kernel)
+// and the locate kernel's queue head.
+static size_t locate_part_bytes(uint64_t R) { return align_up((size_t)R * sizeof(uint32_t), 256) + 256; }
+
+size_t bwtgpu_search_locate_workspace_bytes(uint64_t R, uint32_t m) {
+  return bwtgpu_search_workspace_bytes(R, m) + locate_part_bytes(R);
+}
+
+size_t bwtgpu_search_locate_packed_workspace_bytes(uint64_t R) { return locate_part_bytes(R); }
+
+// the rows at the front of `part`, the queue head behind them
+static int locate_from_rows(const bwtgpu_index *ix, uint8_t *part, uint64_t R, uint32_t *d_pos, hipStream_t s) {
+  return bwtgpu_locate_rows(ix, reinterpret_cast<const uint32_t *>(part), R, d_pos, nullptr,
+                            part + align_up((size_t)R * sizeof(uint32_t), 256), 256, (void *)s);
+}
+
+int bwtgpu_search_locate(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride, uint64_t R,
+                         uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_pos, void *d_ws, size_t ws_bytes, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!ix || !d_pos) return set_error(kErrArg, "null argument");
+  if (!d_ws || ((uintptr_t)d_ws & 255u)) return set_error(kErrArg, "workspace must be 256-byte aligned");
+  if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
+  BWT_TRY(index_ready_for_search(ix, s));
+  if (ix->d_isa)  // the kernel knows the position of nearly every read by the time it has its interval
+    return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, d_pos, d_ws, ws_bytes, nullptr, s);
+  if (ws_bytes < bwtgpu_search_locate_workspace_bytes(R, m))
+    return set_error(kErrWorkspace, "search-and-locate workspace %zu < %zu bytes", ws_bytes,
+                     bwtgpu_search_locate_workspace_bytes(R, m));
+  if (!ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
+  const size_t sws = bwtgpu_search_workspace_bytes(R, m);
+  uint8_t *part = (uint8_t *)d_ws + sws;
+  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, reinterpret_cast<uint32_t *>(part), nullptr, d_ws, sws,
+                      nullptr, s));
+  if (R == 0) return kOk;
+  return locate_from_rows(ix, part, R, d_pos, s);
+}
+
+int bwtgpu_search_locate_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R,
+                                uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_pos, void *d_ws, size_t ws_bytes,
+                                void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  BWT_TRY(packed_args_ok(ix, d_words, m, R, d_sp, d_ep));
+  if (!d_pos) return set_error(kErrArg, "null argument");
+  if (R == 0) return kOk;
+  BWT_TRY(index_ready_for_search(ix, s));
+  if (ix->d_isa) return search_packed_impl(ix, d_words, m, R, d_sp, d_ep, nullptr, d_pos, s);
+  if (!d_ws || ((uintptr_t)d_ws & 255u)) return set_error(kErrArg, "workspace must be 256-byte aligned");
+  if (ws_bytes < locate_part_bytes(R))
+    return set_error(kErrWorkspace, "search-and-locate workspace %zu < %zu bytes", ws_bytes, locate_part_bytes(R));
+  if (!ix->has_samples)
+    return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
+  uint8_t *part = (uint8_t *)d_ws;
+  BWT_TRY(search_packed_impl(ix, d_words, m, R, d_sp, d_ep, reinterpret_cast<uint32_t *>(part), nullptr, s));
+  return locate_from_rows(ix, part, R, d_pos, s);
 }
 
 int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
@@ -668,7 +749,7 @@ int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
                      "%llu reads of %u bases need %zu bytes of scratch, bwtgpu_search_static has %zu: "
                      "split the batch or use bwtgpu_search with a workspace",
                      (unsigned long long)R, m, bwtgpu_search_workspace_bytes(R, m), kStaticScratchBytes);
-  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, d_scratch, kStaticScratchBytes, nullptr,
+  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_scratch, kStaticScratchBytes, nullptr,
                      (hipStream_t)stream);
 }
 
@@ -685,7 +766,7 @@ int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_
   unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_ws);
   if (ix) BWT_TRY(index_ready_for_search(ix, s));
   BWT_HIP(hipMemsetAsync(ctr, 0, 256, s));
-  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
+  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
                       s));
   unsigned long long h[5];
   BWT_HIP(hipMemcpyAsync(h, ctr, sizeof h, hipMemcpyDeviceToHost, s));
@@ -733,3 +814,15 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
 }
 
 }  // extern "C"
+
+namespace bwtgpu {
+
+int search_packed_dev(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,
+                      uint32_t *d_ep, uint32_t *d_locrow, uint32_t *d_pos, hipStream_t s) {
+  BWT_TRY(packed_args_ok(ix, d_words, m, R, d_sp, d_ep));
+  if (d_pos && !ix->d_isa) return set_error(kErrArg, "positions from the search kernel need the position records");
+  if (R == 0) return kOk;
+  return search_packed_impl(ix, d_words, m, R, d_sp, d_ep, d_locrow, d_pos, s);
+}
+
+}  // namespace bwtgpu

@@ -139,6 +139,32 @@ class GpuIndex:
                                 _ptr(ws), ws.numel(), _stream()))
         return (sp, ep, lr) if want_locrow else (sp, ep)
 
+    def search_locate(self, d_pats, m, R, stride=None, out=None):
+        """bwtgpu_search_locate: loc_search and locate() of every read in one call.
+        Returns (sp, ep, pos) as int32 CUDA tensors holding uint32 bits."""
+        lib = _lib.load()
+        stride = m if stride is None else stride
+        need = (R - 1) * stride + m if R else 0
+        if d_pats.numel() < need:
+            raise ValueError(f"pattern buffer holds {d_pats.numel()} bytes, needs {need}")
+        sp, ep, pos = out if out is not None else (torch.empty(R, dtype=torch.int32, device="cuda") for _ in range(3))
+        ws = self._workspace(int(lib.bwtgpu_search_locate_workspace_bytes(R, m)))
+        check(lib.bwtgpu_search_locate(self.h, _ptr(d_pats), m, stride, R, _ptr(sp), _ptr(ep), _ptr(pos),
+                                       _ptr(ws), ws.numel(), _stream()))
+        return sp, ep, pos
+
+    def search_locate_packed(self, d_words, m, R, out=None):
+        """bwtgpu_search_locate_packed: the same for reads packed to 2 bits per base."""
+        lib = _lib.load()
+        wpr = (m + 15) // 16
+        if d_words.numel() < R * wpr:
+            raise ValueError(f"packed buffer holds {d_words.numel()} words, needs {R * wpr}")
+        sp, ep, pos = out if out is not None else (torch.empty(R, dtype=torch.int32, device="cuda") for _ in range(3))
+        ws = self._workspace(int(lib.bwtgpu_search_locate_packed_workspace_bytes(R)))
+        check(lib.bwtgpu_search_locate_packed(self.h, _ptr(d_words), m, R, _ptr(sp), _ptr(ep), _ptr(pos),
+                                              _ptr(ws), ws.numel(), _stream()))
+        return sp, ep, pos
+
     def search_static(self, d_pats, m, R, stride=None, want_locrow=False):
         """bwtgpu_search_static: the same search with the library's own static
         scratch in place of a workspace argument."""

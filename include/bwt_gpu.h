@@ -243,6 +243,26 @@ int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
  * reference, which keeps reads one base per byte. */
 int bwtgpu_search_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R,
                          uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *stream);
+/* loc_search and locate() of every read in one call (the pair the reference's
+ * callers make per read: seqindex.c:280-309 then seqindex.c:258-277, as in
+ * filetest.c and the worker loop fmitest.c:54-65): d_sp, d_ep as bwtgpu_search
+ * leaves them, d_pos[r] = the position locate() returns -- SA[sp], also for an
+ * interval that emptied on the very last step (the reference does not look at
+ * ep there), 0xFFFFFFFF where it returns -1 or sp = n+1.  Same results as
+ * bwtgpu_search with d_locrow followed by bwtgpu_locate_rows.  On an index that
+ * keeps its position records the search kernel writes the positions itself: it
+ * compares the read with the text at a known place, so the position of all but
+ * the repeated reads costs no further load.  Other indexes run the two kernels.
+ * Workspace: bwtgpu_search_locate_workspace_bytes(R, m), 256-byte aligned;
+ * the packed form: bwtgpu_search_locate_packed_workspace_bytes(R). */
+size_t bwtgpu_search_locate_workspace_bytes(uint64_t R, uint32_t m);
+int bwtgpu_search_locate(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m,
+                         uint64_t stride, uint64_t R, uint32_t *d_sp, uint32_t *d_ep,
+                         uint32_t *d_pos, void *d_ws, size_t ws_bytes, void *stream);
+size_t bwtgpu_search_locate_packed_workspace_bytes(uint64_t R);
+int bwtgpu_search_locate_packed(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m,
+                                uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_pos,
+                                void *d_ws, size_t ws_bytes, void *stream);
 /* bwtgpu_search for callers that cannot allocate or hold a workspace (code
  * under HIP graph capture, tight serving loops): no counterpart in the
  * reference.  Same inputs, outputs and results as bwtgpu_search; the packed-read

@@ -62,6 +62,11 @@ def test_headline_configuration_at_full_size(oracle, gpu):
     pos = gpu.to_numpy_u32(ix.locate_rows(lr))
     found = ep_h > sp_h
     np.testing.assert_array_equal(pos[found], sa_h[sp_h[found]])
+    # search and locate in one call: the same three arrays for all 10 M reads
+    a, b, c = ix.search_locate(d_reads, M, R)
+    assert torch.equal(a, sp) and torch.equal(b, ep)
+    np.testing.assert_array_equal(gpu.to_numpy_u32(c), pos)
+    del a, b, c
 
     # bit-exact against the oracle's loc_search on a sample that includes the random reads
     sample = np.concatenate([np.nonzero(~cut)[0][:20000], pick])
@@ -157,6 +162,9 @@ def test_3100_mbp_index_and_search(gpu):
     unique = cut & (epn - spn == 1)
     assert unique.mean() > 0.9
     np.testing.assert_array_equal(posn[unique], offn[unique])
+    a, b, c = ix.search_locate(reads, m, R)  # search and locate in one call: the same three arrays
+    assert torch.equal(a, sp) and torch.equal(b, ep) and torch.equal(c, pos)
+    del a, b, c
     ix.compact()
     sp2, ep2, lr2 = ix.search(reads, m, R, want_locrow=True)
     assert torch.equal(sp2, sp) and torch.equal(ep2, ep) and torch.equal(lr2, lr)

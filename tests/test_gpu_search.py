@@ -176,6 +176,20 @@ def _mutated_reads(text_bases, n, R, m, seed):
     return reads
 
 
+def _check_search_locate(gpu, ix, d, m, R, sp, ep, pos, msg):
+    """bwtgpu_search_locate and its packed form give what the search followed by
+    locate_rows gave (seqindex.c:280-309, then seqindex.c:258-277), array by array."""
+    a, b, c = (gpu.to_numpy_u32(x) for x in ix.search_locate(d, m, R))
+    np.testing.assert_array_equal(a, sp, err_msg=msg)
+    np.testing.assert_array_equal(b, ep, err_msg=msg)
+    np.testing.assert_array_equal(c, pos, err_msg=msg)
+    words = gpu.pack_reads_dev(d, m, R)
+    a, b, c = (gpu.to_numpy_u32(x) for x in ix.search_locate_packed(words, m, R))
+    np.testing.assert_array_equal(a, sp, err_msg=msg + " packed")
+    np.testing.assert_array_equal(b, ep, err_msg=msg + " packed")
+    np.testing.assert_array_equal(c, pos, err_msg=msg + " packed")
+
+
 @pytest.mark.parametrize("n,R,m,kind", [(13, 300, 20, "random"), (40, 600, 9, "random"), (777, 2000, 25, "random"),
                                         (100003, 20000, 50, "random"), (1000000, 20000, 100, "random"),
                                         (200000, 10000, 64, "mutated-repeat"), (50000, 5000, 33, "tandem")],
@@ -208,6 +222,7 @@ def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R
         np.testing.assert_array_equal(ep, ep_o, err_msg=name)
         pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))
         out[name] = (lr, pos)
+        _check_search_locate(gpu, ix, d, m, R, sp, ep, pos, name)
     np.testing.assert_array_equal(out["full"][0], out["lean"][0])
     np.testing.assert_array_equal(out["full"][1], out["lean"][1])
     want = np.array([oracle.locate(fo, reads[r]) for r in range(min(R, 3000))], np.int64)
@@ -273,8 +288,9 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
             np.testing.assert_array_equal(sp, sp_o, err_msg=f"{name} m={m}")
             np.testing.assert_array_equal(ep, ep_o, err_msg=f"{name} m={m}")
             want = np.array([oracle.locate(fo, reads[r]) for r in range(300)], np.int64)
-            pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))[:300]
-            got = pos.astype(np.int64)
+            pos = gpu.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda()))
+            _check_search_locate(gpu, ix, d, m, R, sp, ep, pos, f"{name} m={m}")
+            got = pos[:300].astype(np.int64)
             got[got == 0xFFFFFFFF] = -1
             np.testing.assert_array_equal(got, want, err_msg=f"{name} m={m}")
     loads, _, _ = full.search_loads(torch.from_numpy(reads.reshape(-1)).cuda(), 70, 3000)
