@@ -62,6 +62,10 @@ def test_index_without_sampled_rows_searches_but_refuses_to_locate(oracle, gpu):
     np.testing.assert_array_equal(gpu.to_numpy_u32(ep), ep_o)
     with pytest.raises(gpu.BwtGpuError, match="without sampled"):
         ix.locate_rows(lr)
+    with pytest.raises(gpu.BwtGpuError, match="without sampled"):
+        ix.search_locate(d, m, R)
+    with pytest.raises(gpu.BwtGpuError, match="without sampled"):
+        ix.search_locate_packed(gpu.pack_reads_dev(d, m, R), m, R)
     offs = torch.arange(R + 1, dtype=torch.int64, device="cuda") * m
     out = torch.empty(4 * R, dtype=torch.int32, device="cuda")
     rc = lib.bwtgpu_search_reads(ix.h, d.data_ptr(), None, offs.data_ptr(), R, 20, out.data_ptr(), None)

@@ -125,6 +125,10 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                     pos = G.to_numpy_u32(ix.locate_rows(torch.from_numpy(lr.view(np.int32)).cuda())).astype(np.int64)
                     pos[pos == 0xFFFFFFFF] = -1
                     assert pos.tolist() == want_loc, f"locate() {name} m={m}"
+                    a, b, c = (G.to_numpy_u32(x) for x in ix.search_locate(d, m, R))  # the one-call form
+                    c = c.astype(np.int64); c[c == 0xFFFFFFFF] = -1
+                    assert np.array_equal(a, sp_o) and np.array_equal(b, ep_o) and c.tolist() == want_loc, \
+                        f"search_locate {name} m={m}"
                 readsn = reads_for(rng, bases, n, 200, m, True)
                 want = [orc.mms(fo, readsn[r]) for r in range(200)]
                 for name, ix in (("full", full), ("lean", lean), ("loaded", loaded)):
