@@ -151,18 +151,23 @@ __device__ __forceinline__ uint32_t sym_count(const uint4 &b, uint32_t r) {
 
 // LF mapping (seqindex.c:214-219) for a row in [0, n].  Branch-free so that
 // several independent walks in one lane keep their loads in flight together.
-__device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx) {
+// c: the BWT symbol of the row (meaningless for the $ row).
+__device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx, uint32_t &c) {
   const uint32_t j = idx - (idx > v.endloc);
   const IndexBlock *b = v.blocks + (j >> 6);
   const uint4 occ = *reinterpret_cast<const uint4 *>(b->occ);
   const uint64_t lo = b->lo, hi = b->hi;
   const uint32_t r = j & 63u;
-  const uint32_t c = (uint32_t)((lo >> r) & 1ull) | ((uint32_t)((hi >> r) & 1ull) << 1);
+  c = (uint32_t)((lo >> r) & 1ull) | ((uint32_t)((hi >> r) & 1ull) << 1);
   const uint64_t nlo = (c & 1u) ? 0ull : ~0ull, nhi = (c & 2u) ? 0ull : ~0ull;
   const uint64_t match = (lo ^ nlo) & (hi ^ nhi) & low_mask(r);
   const uint32_t base = c == 0 ? occ.x : c == 1 ? occ.y : c == 2 ? occ.z : occ.w;
   const uint32_t next = base + (uint32_t)__popcll(match);
   return idx == v.endloc ? 0u : next;  // the $ row maps to row 0
+}
+__device__ __forceinline__ uint32_t lf_step(const IndexView &v, uint32_t idx) {
+  uint32_t c;
+  return lf_step(v, idx, c);
 }
 
 }  // namespace bwtgpu

@@ -434,65 +434,178 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
   }
 }
 
-// The text from the suffix array and the BWT: the symbol of row r is the base
-// in front of suffix SA[r] (histsortcomp.c:227-239 read backwards).  text2 is
-// zeroed beforehand; sixteen rows, anywhere in the suffix array, share a word.
-__global__ void k_text_from_bwt(IndexView v, const uint32_t *__restrict__ sa, uint32_t *__restrict__ text2) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r > v.n) return;
-  const uint32_t p = sa[r];
-  if (p == 0 || p > v.n) return;  // the $ row: nothing precedes suffix 0
-  const uint32_t j = (uint32_t)r - ((uint32_t)r > v.endloc);
-  const IndexBlock *b = v.blocks + (j >> 6);
-  const uint32_t c = (uint32_t)((b->lo >> (j & 63u)) & 1ull) | ((uint32_t)((b->hi >> (j & 63u)) & 1ull) << 1);
-  const uint32_t q = p - 1;
-  if (c) atomicOr(&text2[1 + (q >> 4)], c << (2u * (q & 15u)));
+// Suffix array and text of an index that holds the BWT and every 8th row of the
+// suffix array (what a loaded index has once its samples are densified).  Row r
+// with SA[r] = p has BWT symbol text[p - 1], and LF(r) is the row of suffix p - 1
+// (seqindex.c:214-219, the step unc_sa repeats, seqindex.c:244-255): walking LF
+// from a sampled row names row and text position of one suffix after the other,
+// until the next sampled row, where another walk has started.  The sampled rows
+// cut the one cycle of LF into chains, every row lies on exactly one, so a row
+// costs one LF step (walking from every row to its next sample costs 3.5) and
+// the text comes with it.  Chain lengths are geometric: lanes take chains from a
+// device-wide queue as they finish, two chains per lane in flight (cf. k_locate).
+// A chain's text symbols are gathered into the word they share and joined to
+// text2 (zeroed beforehand) by one atomic per word and chain.
+// report[0] += rows written, report[1] += chains given up (not the LF map of a text).
+__global__ void __launch_bounds__(256)
+k_recover_chains(IndexView v, uint64_t chains, uint32_t *__restrict__ sa, uint32_t *__restrict__ text2,
+                 unsigned long long *__restrict__ queue_head, unsigned long long *__restrict__ report) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint64_t loc_lo = 0, loc_hi = 0;  // wave-uniform: chains this wave holds
+  bool exhausted = false;
+  bool active[kLocateSlots];
+  uint32_t idx[kLocateSlots], pos[kLocateSlots], steps[kLocateSlots], tw[kLocateSlots], twi[kLocateSlots];
+#pragma unroll
+  for (int s = 0; s < kLocateSlots; ++s) {
+    active[s] = false;
+    idx[s] = pos[s] = steps[s] = tw[s] = 0;
+    twi[s] = 0xFFFFFFFFu;
+  }
+  unsigned long long written = 0, given_up = 0;
+  for (;;) {
+    uint64_t need[kLocateSlots];
+    uint32_t want = 0;
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) {
+      need[s] = __ballot(!active[s]);
+      want += (uint32_t)__popcll(need[s]);
+    }
+    if (want) {
+      if (loc_lo >= loc_hi && !exhausted) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(queue_head, (unsigned long long)kLocateBatch);
+        base = __shfl(base, 0, 64);
+        if (base >= chains) {
+          exhausted = true;
+          loc_lo = loc_hi = 0;
+        } else {
+          loc_lo = base;
+          loc_hi = base + kLocateBatch < chains ? base + kLocateBatch : chains;
+        }
+      }
+      uint64_t first = loc_lo;
+#pragma unroll
+      for (int s = 0; s < kLocateSlots; ++s) {
+        if (!active[s]) {
+          const uint64_t cand = first + (uint64_t)__popcll(need[s] & low_mask(lane));
+          if (cand < loc_hi) {
+            const uint32_t row = (uint32_t)(cand << kDevSampleShift), p = v.idxs[cand];
+            sa[row] = p;
+            ++written;
+            idx[s] = row;
+            pos[s] = p;
+            steps[s] = 0;
+            tw[s] = 0;
+            twi[s] = 0xFFFFFFFFu;
+            active[s] = true;
+          }
+        }
+        first += (uint64_t)__popcll(need[s]);
+      }
+      loc_lo = first < loc_hi ? first : loc_hi;
+    }
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) any = any || active[s];
+    if (!__any(any)) {
+      if (exhausted && loc_lo >= loc_hi) break;
+      continue;
+    }
+    uint32_t nxt[kLocateSlots], sym[kLocateSlots];
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) nxt[s] = lf_step(v, active[s] ? idx[s] : 0u, sym[s]);
+#pragma unroll
+    for (int s = 0; s < kLocateSlots; ++s) {
+      if (!active[s]) continue;
+      bool done = false;
+      if (idx[s] == v.endloc) {
+        done = true;  // suffix 0: nothing in front of it, and LF leads to row 0, a sampled row
+        if (pos[s] != 0) ++given_up;
+      } else if (pos[s] == 0 || pos[s] > v.n || nxt[s] > v.n || ++steps[s] > v.n) {
+        done = true;  // not the LF map of a text
+        ++given_up;
+      } else {
+        const uint32_t q = pos[s] - 1u, wi = q >> 4;
+        if (wi != twi[s]) {
+          if (tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
+          tw[s] = 0;
+          twi[s] = wi;
+        }
+        tw[s] |= sym[s] << (2u * (q & 15u));
+        idx[s] = nxt[s];
+        pos[s] = q;
+        if (nxt[s] & kDevSampleMask) {
+          sa[nxt[s]] = q;
+          ++written;
+        } else {
+          done = true;  // the chain of that sampled row goes on from here
+        }
+      }
+      if (done) {
+        if (tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
+        tw[s] = 0;
+        active[s] = false;
+      }
+    }
+  }
+  for (int off = 32; off; off >>= 1) {
+    written += __shfl_down(written, off, 64);
+    given_up += __shfl_down(given_up, off, 64);
+  }
+  if (lane == 0) {
+    if (written) atomicAdd(report, written);
+    if (given_up) atomicAdd(report + 1, given_up);
+  }
 }
 
 // An index loaded from its parts (BWT, sampled rows) has everything from which
-// the arrays a built index keeps can be recomputed: every row of the suffix
-// array by the walk unc_sa does (seqindex.c:244-255), then the text from rows
-// and BWT.  With them the loaded index gets position records and a two-word
-// k-mer table like a built one.  Not an error when HBM is short: the index then
-// searches on its rank blocks.  Waits for `s`.
+// the arrays a built index keeps can be recomputed: the suffix array and the
+// text, by walking LF from the sampled rows.  With them the loaded index gets
+// position records and a two-word k-mer table like a built one.  Not an error
+// when HBM is short, or when the walks do not cover every row exactly once (the
+// parts are not those of one text): the index then searches on its rank blocks.
+// Waits for `s`.
 int index_recover_arrays(bwtgpu_index *ix, hipStream_t s) {
   if (ix->d_sa || !ix->has_samples) return kOk;
   const uint32_t n = ix->n;
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
-  unsigned long long *head = nullptr;
+  const uint64_t chains = ((uint64_t)n >> kDevSampleShift) + 1;
+  unsigned long long *head = nullptr;  // [0] the queue, [1] rows written, [2] chains given up
   hipError_t e = pool_alloc(&ix->d_sa, rows * 4);
   if (e == hipSuccess) e = pool_alloc(&ix->d_text2, t2words * 4);
   if (e == hipSuccess) e = pool_alloc(&head, 256);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
+  auto drop = [&] {
     pool_free(ix->d_sa);
     pool_free(ix->d_text2);
-    pool_free(head);
     ix->d_sa = ix->d_text2 = nullptr;
+  };
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    drop();
+    pool_free(head);
     return kOk;
   }
   IndexView v = view_of(ix);
-  v.sa = nullptr;  // the walks must not read what they are writing
+  v.sa = nullptr;  // being written
+  unsigned long long report[2] = {0, 0};
   e = hipMemsetAsync(head, 0, 256, s);
   if (e == hipSuccess) e = hipMemsetAsync(ix->d_text2, 0, t2words * 4, s);
   if (e == hipSuccess) {
-    uint64_t groups = div_up(div_up(rows, (uint64_t)kLocateBatch), 4);
+    uint64_t groups = div_up(div_up(chains, (uint64_t)kLocateBatch), 4);
     if (groups > 256 * 8) groups = 256 * 8;
-    BWT_LAUNCH("recover_sa", k_locate, dim3((unsigned)groups), dim3(256), 0, s, v, (const uint32_t *)nullptr, rows,
-               ix->d_sa, (unsigned long long *)nullptr, head);
-    BWT_LAUNCH("recover_text", k_text_from_bwt, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, v,
-               (const uint32_t *)ix->d_sa, ix->d_text2);
+    BWT_LAUNCH("recover_sa_text", k_recover_chains, dim3((unsigned)groups), dim3(256), 0, s, v, chains, ix->d_sa,
+               ix->d_text2, head, head + 1);
     e = hipGetLastError();
   }
+  if (e == hipSuccess) e = hipMemcpyAsync(report, head + 1, sizeof report, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   pool_free(head);
   if (e != hipSuccess) {
     (void)hipDeviceSynchronize();
-    pool_free(ix->d_sa);
-    pool_free(ix->d_text2);
-    ix->d_sa = ix->d_text2 = nullptr;
+    drop();
     return set_error(kErrHip, "recovering the suffix array of a loaded index: %s", hipGetErrorString(e));
   }
+  if (report[0] != rows || report[1] != 0) drop();  // inconsistent parts: stay on the rank blocks
   return kOk;
 }
 
