@@ -250,6 +250,11 @@ int static_scratch_setup(int device, void **out = nullptr);
 
 // hoststream.hip: host batches through pinned staging, packed on the way
 bool host_batch_prefers_packing(uint32_t m, uint64_t stride, uint64_t R);
+// search.hip: walks along LF from sampled rows (k_chain_walk); dense: every 8th row from every 32nd
+// (d_out = the dense samples), else suffix array and text from every 8th row.  Waits for s.
+struct IndexView;
+int chain_walk(const IndexView &v, bool dense, const uint32_t *d_samples, uint64_t chains, uint32_t *d_out,
+               uint32_t *d_text2, uint64_t expect, bool *consistent, hipStream_t s);
 // search.hip: the packed-read search with both optional outputs, rows (d_locrow) and
 // positions (d_pos; only an index with position records, ix->d_isa, can fill those)
 int search_packed_dev(const bwtgpu_index *ix, const uint32_t *d_words, uint32_t m, uint64_t R, uint32_t *d_sp,

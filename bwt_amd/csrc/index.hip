@@ -286,27 +286,6 @@ __global__ void k_build_sym(const IndexBlock *__restrict__ blocks, uint64_t nblo
   }
 }
 
-// Stored samples (every 32nd row) -> HBM samples (every 8th): rows that the
-// file has are copied, the others are found by the walk unc_sa itself does
-// (seqindex.c:244-255) down to the next stored row.
-__global__ void k_densify_samples(IndexView v, const uint32_t *__restrict__ stored, uint64_t ndense,
-                                  uint32_t *__restrict__ dense, uint32_t *__restrict__ broken) {
-  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= ndense) return;
-  uint32_t idx = (uint32_t)(q << kDevSampleShift), steps = 0;
-  while (idx & ((1u << kFileSampleShift) - 1u)) {
-    idx = lf_step(v, idx);
-    if (++steps > v.n || idx > v.n) {  // the parts do not belong to one index
-      *broken = 1u;
-      dense[q] = 0xFFFFFFFFu;
-      return;
-    }
-  }
-  uint64_t x = (uint64_t)stored[idx >> kFileSampleShift] + steps;
-  if (x > v.n) x -= (uint64_t)v.n + 1;
-  dense[q] = (uint32_t)x;
-}
-
 __global__ void k_thin_samples(const uint32_t *__restrict__ dense, uint64_t nstored,
                                uint32_t *__restrict__ stored) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -724,23 +703,15 @@ bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n, uint32_t
   // then makes the search-only arrays a built index has (index_recover_arrays)
   ix->want_recover = h_idxs != nullptr && !getenv("BWT_MI355X_COMPACT") && n <= kPosRecordMaxN;
   if (rc == kOk) index_defer_search_arrays(ix);  // ... and the k-mer table
-  uint32_t broken = 0;
   if (rc == kOk && h_idxs) {
-    // the first word of the (no longer needed) BWT staging buffer takes the "walk did not end" flag
-    uint32_t *d_broken = reinterpret_cast<uint32_t *>(d_bwt);
-    if (hipMemsetAsync(d_broken, 0, 4, s) != hipSuccess) rc = set_error(kErrHip, "sample densify failed");
-    if (rc == kOk) {
-      ScopedKernelTimer t("densify_samples", s);
-      hipLaunchKernelGGL(k_densify_samples, dim3((unsigned)div_up(ndense, 256)), dim3(256), 0, s,
-                         view_of(ix), d_stored, (uint64_t)ndense, ix->d_idxs, d_broken);
-    }
-    if (rc == kOk && hipMemcpyAsync(&broken, d_broken, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
-      rc = set_error(kErrHip, "sample densify failed");
+    // stored samples (every 32nd row) -> HBM samples (every 8th): walks along LF from the stored rows
+    bool consistent = false;
+    rc = chain_walk(view_of(ix), true, d_stored, nstored, ix->d_idxs, nullptr, ndense, &consistent, s);
+    if (rc == kOk && !consistent)
+      rc = set_error(kErrArg, "index parts are inconsistent: the walks along LF from the stored rows do not pass "
+                              "every row once (wrong $ row, or BWT and sampled rows of different texts)");
   }
-  if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "sample densify failed");
-  if (rc == kOk && broken)
-    rc = set_error(kErrArg, "index parts are inconsistent: walking LF from a row never reaches a stored row "
-                            "(wrong $ row, or BWT and sampled rows of different texts)");
+  if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "index load failed");
   (void)hipFree(d_bwt);
   if (d_stored) (void)hipFree(d_stored);
   if (rc != kOk) {

@@ -434,22 +434,31 @@ k_locate(IndexView v, const uint32_t *__restrict__ rows, uint64_t R, uint32_t *_
   }
 }
 
-// Suffix array and text of an index that holds the BWT and every 8th row of the
-// suffix array (what a loaded index has once its samples are densified).  Row r
-// with SA[r] = p has BWT symbol text[p - 1], and LF(r) is the row of suffix p - 1
-// (seqindex.c:214-219, the step unc_sa repeats, seqindex.c:244-255): walking LF
-// from a sampled row names row and text position of one suffix after the other,
-// until the next sampled row, where another walk has started.  The sampled rows
-// cut the one cycle of LF into chains, every row lies on exactly one, so a row
-// costs one LF step (walking from every row to its next sample costs 3.5) and
-// the text comes with it.  Chain lengths are geometric: lanes take chains from a
-// device-wide queue as they finish, two chains per lane in flight (cf. k_locate).
-// A chain's text symbols are gathered into the word they share and joined to
-// text2 (zeroed beforehand) by one atomic per word and chain.
-// report[0] += rows written, report[1] += chains given up (not the LF map of a text).
+// Walks along LF from sampled rows of the suffix array.  Row r with SA[r] = p has
+// BWT symbol text[p - 1], and LF(r) is the row of suffix p - 1 (seqindex.c:214-219,
+// the step unc_sa repeats, seqindex.c:244-255): walking LF from a sampled row
+// names row and text position of one suffix after the other, until the next
+// sampled row, where another walk has started.  The sampled rows cut the one
+// cycle of LF into chains and every row lies on exactly one, so a row costs one
+// LF step (walking from every row to its next sample costs half the sample
+// distance).  Chain lengths are geometric: lanes take chains from a device-wide
+// queue as they finish, two chains per lane in flight (cf. k_locate).
+//
+// DENSE = false: suffix array and text of an index that holds every 8th row
+//   (`samples`): out = sa[n + 1]; a chain's text symbols are gathered into the
+//   word they share and joined to text2 (zeroed beforehand) by one atomic per
+//   word and chain.
+// DENSE = true: every 8th row from every 32nd (`samples`, what an index file
+//   stores, fileio.c:14): out = the dense samples.
+// report[0] += entries of `out` written, report[1] += chains given up (not the LF map of a text) or
+// arriving at a sampled row with another position than the one stored for it.
+template <bool DENSE>
 __global__ void __launch_bounds__(256)
-k_recover_chains(IndexView v, uint64_t chains, uint32_t *__restrict__ sa, uint32_t *__restrict__ text2,
-                 unsigned long long *__restrict__ queue_head, unsigned long long *__restrict__ report) {
+k_chain_walk(IndexView v, const uint32_t *__restrict__ samples, uint64_t chains, uint32_t *__restrict__ out,
+             uint32_t *__restrict__ text2, unsigned long long *__restrict__ queue_head,
+             unsigned long long *__restrict__ report) {
+  constexpr uint32_t kShift = DENSE ? kFileSampleShift : kDevSampleShift;  // rows between chain starts
+  constexpr uint32_t kMask = (1u << kShift) - 1u;
   const uint32_t lane = threadIdx.x & 63u;
   uint64_t loc_lo = 0, loc_hi = 0;  // wave-uniform: chains this wave holds
   bool exhausted = false;
@@ -489,8 +498,8 @@ k_recover_chains(IndexView v, uint64_t chains, uint32_t *__restrict__ sa, uint32
         if (!active[s]) {
           const uint64_t cand = first + (uint64_t)__popcll(need[s] & low_mask(lane));
           if (cand < loc_hi) {
-            const uint32_t row = (uint32_t)(cand << kDevSampleShift), p = v.idxs[cand];
-            sa[row] = p;
+            const uint32_t row = (uint32_t)(cand << kShift), p = samples[cand];
+            out[DENSE ? row >> kDevSampleShift : row] = p;
             ++written;
             idx[s] = row;
             pos[s] = p;
@@ -525,24 +534,31 @@ k_recover_chains(IndexView v, uint64_t chains, uint32_t *__restrict__ sa, uint32
         done = true;  // not the LF map of a text
         ++given_up;
       } else {
-        const uint32_t q = pos[s] - 1u, wi = q >> 4;
-        if (wi != twi[s]) {
-          if (tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
-          tw[s] = 0;
-          twi[s] = wi;
+        const uint32_t q = pos[s] - 1u;
+        if (!DENSE) {
+          const uint32_t wi = q >> 4;
+          if (wi != twi[s]) {
+            if (tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
+            tw[s] = 0;
+            twi[s] = wi;
+          }
+          tw[s] |= sym[s] << (2u * (q & 15u));
         }
-        tw[s] |= sym[s] << (2u * (q & 15u));
         idx[s] = nxt[s];
         pos[s] = q;
-        if (nxt[s] & kDevSampleMask) {
-          sa[nxt[s]] = q;
+        if ((nxt[s] & kMask) == 0) {
+          done = true;  // the chain of that sampled row goes on from here, and from this position
+          if (samples[nxt[s] >> kShift] != q) ++given_up;
+        } else if (!DENSE) {
+          out[nxt[s]] = q;
           ++written;
-        } else {
-          done = true;  // the chain of that sampled row goes on from here
+        } else if ((nxt[s] & kDevSampleMask) == 0) {
+          out[nxt[s] >> kDevSampleShift] = q;
+          ++written;
         }
       }
       if (done) {
-        if (tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
+        if (!DENSE && tw[s]) atomicOr(&text2[1u + twi[s]], tw[s]);
         tw[s] = 0;
         active[s] = false;
       }
@@ -558,6 +574,35 @@ k_recover_chains(IndexView v, uint64_t chains, uint32_t *__restrict__ sa, uint32
   }
 }
 
+// Runs the walks and waits for them.  *consistent: every one of the `expect` entries was
+// written exactly once and no chain was given up.
+int chain_walk(const IndexView &v, bool dense, const uint32_t *d_samples, uint64_t chains, uint32_t *d_out,
+               uint32_t *d_text2, uint64_t expect, bool *consistent, hipStream_t s) {
+  unsigned long long *head = nullptr;  // [0] the queue, [1] entries written, [2] chains given up
+  *consistent = false;
+  BWT_HIP(pool_alloc(&head, 256));
+  unsigned long long report[2] = {0, 0};
+  hipError_t e = hipMemsetAsync(head, 0, 256, s);
+  if (e == hipSuccess) {
+    uint64_t groups = div_up(div_up(chains, (uint64_t)kLocateBatch), 4);
+    if (groups > 256 * 8) groups = 256 * 8;
+    if (dense)
+      BWT_LAUNCH("densify_samples", k_chain_walk<true>, dim3((unsigned)groups), dim3(256), 0, s, v, d_samples, chains,
+                 d_out, d_text2, head, head + 1);
+    else
+      BWT_LAUNCH("recover_sa_text", k_chain_walk<false>, dim3((unsigned)groups), dim3(256), 0, s, v, d_samples,
+                 chains, d_out, d_text2, head, head + 1);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(report, head + 1, sizeof report, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) (void)hipDeviceSynchronize();
+  pool_free(head);
+  if (e != hipSuccess) return set_error(kErrHip, "walking LF from the sampled rows: %s", hipGetErrorString(e));
+  *consistent = report[0] == expect && report[1] == 0;
+  return kOk;
+}
+
 // An index loaded from its parts (BWT, sampled rows) has everything from which
 // the arrays a built index keeps can be recomputed: the suffix array and the
 // text, by walking LF from the sampled rows.  With them the loaded index gets
@@ -569,44 +614,26 @@ int index_recover_arrays(bwtgpu_index *ix, hipStream_t s) {
   if (ix->d_sa || !ix->has_samples) return kOk;
   const uint32_t n = ix->n;
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
-  const uint64_t chains = ((uint64_t)n >> kDevSampleShift) + 1;
-  unsigned long long *head = nullptr;  // [0] the queue, [1] rows written, [2] chains given up
-  hipError_t e = pool_alloc(&ix->d_sa, rows * 4);
-  if (e == hipSuccess) e = pool_alloc(&ix->d_text2, t2words * 4);
-  if (e == hipSuccess) e = pool_alloc(&head, 256);
   auto drop = [&] {
     pool_free(ix->d_sa);
     pool_free(ix->d_text2);
     ix->d_sa = ix->d_text2 = nullptr;
   };
+  hipError_t e = pool_alloc(&ix->d_sa, rows * 4);
+  if (e == hipSuccess) e = pool_alloc(&ix->d_text2, t2words * 4);
+  if (e == hipSuccess) e = hipMemsetAsync(ix->d_text2, 0, t2words * 4, s);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     drop();
-    pool_free(head);
     return kOk;
   }
   IndexView v = view_of(ix);
   v.sa = nullptr;  // being written
-  unsigned long long report[2] = {0, 0};
-  e = hipMemsetAsync(head, 0, 256, s);
-  if (e == hipSuccess) e = hipMemsetAsync(ix->d_text2, 0, t2words * 4, s);
-  if (e == hipSuccess) {
-    uint64_t groups = div_up(div_up(chains, (uint64_t)kLocateBatch), 4);
-    if (groups > 256 * 8) groups = 256 * 8;
-    BWT_LAUNCH("recover_sa_text", k_recover_chains, dim3((unsigned)groups), dim3(256), 0, s, v, chains, ix->d_sa,
-               ix->d_text2, head, head + 1);
-    e = hipGetLastError();
-  }
-  if (e == hipSuccess) e = hipMemcpyAsync(report, head + 1, sizeof report, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);
-  pool_free(head);
-  if (e != hipSuccess) {
-    (void)hipDeviceSynchronize();
-    drop();
-    return set_error(kErrHip, "recovering the suffix array of a loaded index: %s", hipGetErrorString(e));
-  }
-  if (report[0] != rows || report[1] != 0) drop();  // inconsistent parts: stay on the rank blocks
-  return kOk;
+  bool consistent = false;
+  const int rc = chain_walk(v, false, ix->d_idxs, ((uint64_t)n >> kDevSampleShift) + 1, ix->d_sa, ix->d_text2, rows,
+                            &consistent, s);
+  if (rc != kOk || !consistent) drop();  // inconsistent parts: stay on the rank blocks
+  return rc;
 }
 
 // Scratch of bwtgpu_search_static: the packed reads of a batch whose reads are

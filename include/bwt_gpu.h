@@ -127,15 +127,21 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n,
                                          uint32_t endloc, void *stream);
 /* Replaces the rebuild half of read_index (fileio.c:44-63): takes the stored
  * parts of an index (host pointers) and rebuilds the rank blocks on device.
- * h_idxs may be NULL (no locate on such an index).
+ * h_idxs may be NULL (no locate on such an index).  The device keeps every 8th
+ * row: the missing ones are found by walking LF (seqindex.c:214-219) from the
+ * stored rows, one step per row of the index, and the load is refused (NULL,
+ * "index parts are inconsistent") unless those walks pass every row once and
+ * each arrives at the next stored row with the position stored for it -- BWT,
+ * $ row and sampled rows then belong to one text.
  * BWT and sampled rows determine the suffix array and the text: the first batch
  * search on a loaded index (or bwtgpu_index_prepare_search) recomputes both on
- * the device -- every row by the walk unc_sa does (seqindex.c:244-255), the text
- * from rows and BWT -- and then makes the search-only arrays an index built from
- * the text has, so a loaded index searches as fast as a built one.  This costs
- * about 3.5 LF steps per base once (4 ms at 46 Mbp, 0.3 s at 3.1 Gbp) and the
- * memory bwtgpu_index_compact describes; bwtgpu_index_keep_lean, that call, or
- * BWT_MI355X_COMPACT in the environment keep the index as loaded. */
+ * the device by the same walks (row and text position of one suffix after the
+ * other, the BWT symbol being the base in front) and then makes the search-only
+ * arrays an index built from the text has, so a loaded index searches as fast
+ * as a built one.  This costs one LF step per base once (1.5 ms at 46 Mbp,
+ * 0.16 s at 3.1 Gbp) and the memory bwtgpu_index_compact describes;
+ * bwtgpu_index_keep_lean, that call, or BWT_MI355X_COMPACT in the environment
+ * keep the index as loaded. */
 bwtgpu_index *bwtgpu_index_from_parts(const uint8_t *h_bwt, uint32_t n,
                                       uint32_t endloc, const uint32_t *h_idxs,
                                       void *stream);

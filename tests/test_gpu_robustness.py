@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 def test_inconsistent_parts_end_in_an_error_or_an_index_never_in_a_hang(oracle, gpu):
     """read_index hands the device whatever the file holds.  With a wrong $ row the
-    LF map need not be one cycle; walks are cut off, and a load whose walks never
-    reach a stored row is refused."""
+    LF map need not be one cycle; walks are cut off, and a load whose walks from the
+    stored rows do not pass every row once, each arriving at the next stored row with
+    the position stored for it, is refused."""
     for n in (40, 97, 200, 5000):
         text = oracle.gen_genome(n, 11 + n)
         fo = oracle.make_fmi(text, n)
@@ -40,11 +41,17 @@ def test_inconsistent_parts_end_in_an_error_or_an_index_never_in_a_hang(oracle, 
         rows = torch.arange(0, n + 1, dtype=torch.int32, device="cuda")
         np.testing.assert_array_equal(gpu.to_numpy_u32(ix.locate_rows(rows)), oracle.histsort(text, n))
         ix.close()
-    # samples of another text: the BWT is sound, the walks end, the positions are simply not this text's
+    # samples of another text: the BWT is sound and every walk ends, but the positions the walks
+    # arrive with are not the ones stored for the rows they arrive at
     n = 5000
     a, b = oracle.make_fmi(oracle.gen_genome(n, 1), n), oracle.make_fmi(oracle.gen_genome(n, 2), n)
-    ix = gpu.index_from_parts(a.bwt, n, a.endloc, b.idxs)
-    ix.close()
+    with pytest.raises(gpu.BwtGpuError, match="inconsistent"):
+        gpu.index_from_parts(a.bwt, n, a.endloc, b.idxs)
+    # one stored row off by one: refused as well
+    idxs = a.idxs.copy()
+    idxs[len(idxs) // 2] ^= 1
+    with pytest.raises(gpu.BwtGpuError, match="inconsistent"):
+        gpu.index_from_parts(a.bwt, n, a.endloc, idxs)
 
 
 def test_index_without_sampled_rows_searches_but_refuses_to_locate(oracle, gpu):
