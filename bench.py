@@ -363,6 +363,8 @@ def main():
     ap.add_argument("--no-callers", action="store_true", help="skip the mms / search_reads / align figures")
     ap.add_argument("--sharded-timeout", type=float, default=240.0,
                     help="seconds the multi-rank sharded build may take before it is reported as stuck")
+    ap.add_argument("--sharded-genome-bp", type=int, default=250_000_000,
+                    help="N>1: genome of the second sharded-build leg (BASELINE.json configs[2]); 0 skips it")
     ap.add_argument("--cpu-port", action="store_true", help="time the oracle port even if oracle/_ref exists")
     args = ap.parse_args()
     dflt = {"c2": (46_000_000, 10_000_000, 50), "c4": (3_100_000_000, 100_000_000, 100)}[args.config]
@@ -516,42 +518,72 @@ def main():
         """HP1 sharded: one bucket range of the suffix array sorted per rank; the ranks all-gather
         the index products of their rows (2-bit BWT symbols + every 8th row), every rank assembles
         its index.  Timed with and without the second exchange (the rows themselves, for the
-        search-only position records)."""
-        try:
-            out = {}
+        search-only position records).  Twice: on the genome of this run, and on BASELINE.json
+        configs[2] -- a 250 Mbp genome, the SA build sharded by bucket range -- with the whole
+        build of the same text on one GPU timed beside it."""
+
+        def one_text(text, nn, whole_ix, tag):
+            res = {}
             for key, want_sa in (("index", False), ("index_and_suffix_array", True)):
-                phase["at"] = f"sharded build ({key}) warm-up"
-                ixs, how = G.build_index_sharded(d_text, n, want_sa=want_sa)  # workspace, RCCL channels
+                phase["at"] = f"sharded build {tag}({key}) warm-up"
+                ixs, how = G.build_index_sharded(text, nn, want_sa=want_sa)  # workspace, RCCL channels
                 ixs.close()
-                phase["at"] = f"sharded build ({key}) barrier"
+                phase["at"] = f"sharded build {tag}({key}) barrier"
                 barrier()
                 t0 = time.perf_counter()
-                phase["at"] = f"sharded build ({key}) timed run"
-                ixs, how = G.build_index_sharded(d_text, n, want_sa=want_sa)
+                phase["at"] = f"sharded build {tag}({key}) timed run"
+                ixs, how = G.build_index_sharded(text, nn, want_sa=want_sa)
                 barrier()
                 ts = time.perf_counter() - t0
-                same = ixs.C == ix.C and ixs.endloc == ix.endloc
+                same = ixs.C == whole_ix.C and ixs.endloc == whole_ix.endloc
                 if same:
-                    probe, _ = G.gen_reads(d_text, n, 100000, m, 4242, want_offsets=False)
-                    a = ix.search(probe, m, 100000, want_locrow=True)
+                    probe, _ = G.gen_reads(text, nn, 100000, m, 4242, want_offsets=False)
+                    a = whole_ix.search(probe, m, 100000, want_locrow=True)
                     b = ixs.search(probe, m, 100000, want_locrow=True)
                     same = all(torch.equal(x, y) for x, y in zip(a, b))
                     if want_sa:
-                        rep = ixs.certify(d_text)
+                        rep = ixs.certify(text)
                         same = same and all(v == 0 for v in rep.values())
                 ixs.close()
-                phase["at"] = f"sharded build ({key}) all-reduce of the time"
+                phase["at"] = f"sharded build {tag}({key}) all-reduce of the time"
                 tt = torch.tensor([ts], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 t_max = float(tt.item())
-                out[key] = {"how": how, "wall_ms": t_max * 1e3, "value": n / t_max / 1e6, "unit": "Mbp/s",
+                res[key] = {"how": how, "wall_ms": t_max * 1e3, "value": nn / t_max / 1e6, "unit": "Mbp/s",
                             "same_as_whole_build": bool(same),
                             "roofline": {"bound": "hbm", "bytes_per_bp": 5.625,
-                                         "achieved": 5.625 * n / t_max / 1e9, "peak": HBM_PEAK_GBS * world,
-                                         "unit": "GB/s", "frac": 5.625 * n / t_max / 1e9 / (HBM_PEAK_GBS * world)}}
+                                         "achieved": 5.625 * nn / t_max / 1e9, "peak": HBM_PEAK_GBS * world,
+                                         "unit": "GB/s", "frac": 5.625 * nn / t_max / 1e9 / (HBM_PEAK_GBS * world)}}
+            return res
+
+        try:
+            out = one_text(d_text, n, ix, "")
             out["what"] = ("text replicated; each rank sorts one bucket range and the ranks all-gather 0.75 B/base "
                            "of index products over RCCL (index); then 4 B/base of rows for the position records "
                            "(index_and_suffix_array)")
+            n3 = args.sharded_genome_bp
+            if n3:
+                phase["at"] = "250 Mbp genome: whole build on one GPU"
+                text3 = G.gen_genome(n3, synth.GENOME_SEED)
+                whole_ms = []
+                whole = None
+                for _ in range(3):
+                    if whole is not None:
+                        whole.close()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    whole = G.build_index_dev(text3, n3)
+                    torch.cuda.synchronize()
+                    whole_ms.append((time.perf_counter() - t0) * 1e3)
+                big = one_text(text3, n3, whole, "of the 250 Mbp genome ")
+                whole.close()
+                big["genome_bp"] = n3
+                big["whole_build_one_gpu_ms"] = min(whole_ms[1:])
+                big["index_ready_vs_one_gpu"] = big["index"]["wall_ms"] / big["whole_build_one_gpu_ms"]
+                big["what"] = ("BASELINE.json configs[2]: SA build of a 250 Mbp genome sharded by bucket range over "
+                               "the ranks; whole_build_one_gpu_ms is make_fmi of the same text on this rank alone")
+                out["c3_250mbp"] = big
+                del text3
             phase["at"] = "done"
             return out
         except Exception as e:  # noqa: BLE001 - the search figures do not depend on this

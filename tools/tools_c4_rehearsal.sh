@@ -20,5 +20,5 @@ python - <<PY
 import json
 for line in open("$OUT/c2_two_ranks.json"):
     if line.startswith("{"):
-        d = json.loads(line); print({k: d[k] for k in ("value", "n_gpus", "scaling", "ms_per_step")}); print(json.dumps(d["sa_build_sharded"])[:1500])
+        d = json.loads(line); print({k: d[k] for k in ("value", "n_gpus", "scaling", "ms_per_step")}); print(json.dumps(d["sa_build_sharded"])[:4000])
 PY
