@@ -8,7 +8,7 @@ timeout -k 10 300 python3 -u bench.py --config c4 --steps 5 --warmup 2 > $OUT/c4
 python3 - <<PY
 import json; d=json.load(open("$OUT/c4_bench.json"))
 print("c4 reads/s %.4g ms/step %.2f frac %.3f checks %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["checks"]))
-print("c4 build", d["sa_build"]["wall_ms"], d["sa_build"]["search_arrays_ms"], "locate", d["locate"])
+print("c4 build", d["sa_build"]["wall_ms"], d["sa_build"]["search_arrays_ms"], "two calls", d["search_then_locate"])
 PY
 export TMPDIR=/tmp; cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --config c4 --steps 5 --warmup 2 > $OUT/trace_bench.json 2> $OUT/trace.err
