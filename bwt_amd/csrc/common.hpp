@@ -215,7 +215,10 @@ struct bwtgpu_index {
   // Words per table entry: 1 = the interval start alone; 2 = the start and, next to it,
   // SA[start] -- the text position of the string when it occurs exactly once (half of
   // all strings of ceil(log4 n) bases that occur at all), which saves such a search the
-  // suffix-array line.  Two words when the index keeps its suffix array.
+  // suffix-array line.  Two words when the index keeps its suffix array.  For a string
+  // that occurs a few times (2 .. 15 rows) the second word holds the BWT symbols of its
+  // rows instead (kmer_rows_with, fm_device.hpp): a search whose next base goes on with
+  // exactly one of them is down to one row without a rank query.
   uint32_t kmer_w = 1;
   // Two-word entries, when text positions leave bits of the second word free (n < 2^30):
   // its top kmer_sizebits bits hold the number of rows of the interval, capped at

@@ -109,6 +109,28 @@ __device__ __forceinline__ uint32_t kmer_interval(const IndexView &v, uint32_t x
   return kmer_interval(v, x, sp, pos);
 }
 
+// Second word of a two-word table entry whose interval has from 2 to
+// kmer_symbol_rows() rows: instead of a position (of use only when the interval is
+// a single row) it holds the BWT symbols of the interval's rows, row t at bits
+// 2t, and a flag above them in bit F - 1, F = 32 - kmer_sizebits being the width
+// of the field.  The flag is clear when the $ row lies inside the interval.  With
+// the symbols a search knows which rows go on with its next base without a rank
+// query: if it is exactly one, that row's suffix decides everything that follows.
+__device__ __forceinline__ uint32_t kmer_symbol_rows(uint32_t sizebits) {
+  const uint32_t rows = (32u - sizebits - 1u) / 2u;
+  return rows < 15u ? rows : 15u;
+}
+
+// The rows of [sp, sp + size) whose BWT symbol is c, as a mask with bit 2t set for row t;
+// 0 when the entry holds no symbols (see above).  `field` is the entry's second word
+// without its size bits.
+__device__ __forceinline__ uint32_t kmer_rows_with(uint32_t field, uint32_t size, uint32_t sizebits, uint32_t c) {
+  const uint32_t F = 32u - sizebits;
+  if (size < 2u || size > kmer_symbol_rows(sizebits) || !((field >> (F - 1u)) & 1u)) return 0u;
+  const uint32_t x = field ^ (c * 0x55555555u);
+  return ~(x | (x >> 1)) & 0x55555555u & ((1u << (2u * size)) - 1u);
+}
+
 // 16 bases of text starting at position o (o >= -15), base k of the result at
 // bits 2k; text2[0] is a guard word so that o may reach 15 below zero.
 __device__ __forceinline__ uint32_t text16(const uint32_t *__restrict__ text2, int64_t o) {

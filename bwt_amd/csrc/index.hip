@@ -316,6 +316,43 @@ __device__ __forceinline__ void kmer_extend(const IndexView &v, uint2 iv, uint2 
   }
 }
 
+// Second word of a two-word entry (see kmer_interval / kmer_rows_with in fm_device.hpp):
+// SA[start] for an interval of one row (and for intervals too large for symbols),
+// the BWT symbols of its rows for an interval of 2 .. kmer_symbol_rows() rows, and
+// the interval's size in the top `sizebits` bits.
+__device__ __forceinline__ uint32_t kmer_second_word(const IndexView &v, uint2 iv, const uint32_t *__restrict__ sa,
+                                                    uint32_t sizebits) {
+  const uint32_t size = iv.y > iv.x ? iv.y - iv.x : 0u;
+  uint32_t second = 0;
+  if (size >= 2u && size <= kmer_symbol_rows(sizebits) && iv.y <= v.n + 1u) {
+    if (v.endloc < iv.x || v.endloc >= iv.y) {  // else the $ row lies inside: no symbols, flag clear
+      // the rows are up to 15 neighbouring bits of the two planes, in one block or two
+      const uint32_t j0 = iv.x - (iv.x > v.endloc), off = j0 & 63u;
+      const IndexBlock *b = v.blocks + (j0 >> 6);
+      uint64_t lo = b->lo >> off, hi = b->hi >> off;
+      if (off + size > 64u) {
+        lo |= b[1].lo << (64u - off);
+        hi |= b[1].hi << (64u - off);
+      }
+      auto spread = [](uint32_t x) {  // bit t -> bit 2t, t < 16
+        x = (x | (x << 8)) & 0x00FF00FFu;
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        return (x | (x << 1)) & 0x55555555u;
+      };
+      const uint32_t keep = (1u << size) - 1u;
+      second = spread((uint32_t)lo & keep) | (spread((uint32_t)hi & keep) << 1) | (1u << (32u - sizebits - 1u));
+    }
+  } else if (size && iv.x <= v.n) {
+    second = sa[iv.x];
+  }
+  if (sizebits) {  // the interval's size in the bits a text position leaves free (see bwtgpu_index)
+    const uint32_t cap = (1u << sizebits) - 1u;
+    second |= (size < cap ? size : cap) << (32u - sizebits);
+  }
+  return second;
+}
+
 template <bool LAST>
 __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ dst,
                              uint32_t *__restrict__ dst_start, uint32_t j, const uint32_t *__restrict__ sa,
@@ -333,14 +370,8 @@ __global__ void k_kmer_level(IndexView v, const uint2 *__restrict__ src, uint2 *
     kmer_extend(v, iv, o);
     uint2 *entries = reinterpret_cast<uint2 *>(dst_start);
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) {
-      uint32_t second = (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u;
-      if (sizebits) {  // the interval's size in the bits a text position leaves free (see bwtgpu_index)
-        const uint32_t cap = (1u << sizebits) - 1u, size = o[c].y > o[c].x ? o[c].y - o[c].x : 0u;
-        second |= (size < cap ? size : cap) << (32u - sizebits);
-      }
-      entries[(uint64_t)c * parents + p] = make_uint2(o[c].x, second);
-    }
+    for (uint32_t c = 0; c < 4; ++c)
+      entries[(uint64_t)c * parents + p] = make_uint2(o[c].x, kmer_second_word(v, o[c], sa, sizebits));
     return;
   }
   if (LAST) {
@@ -375,21 +406,14 @@ k_kmer_last_two(IndexView v, const uint2 *__restrict__ src, uint2 *__restrict__ 
   if (g >= grand) return;
   uint2 mid[4];
   kmer_extend(v, src[g], mid);
-  const uint32_t cap = sizebits ? (1u << sizebits) - 1u : 0u;
 #pragma unroll
   for (uint32_t c1 = 0; c1 < 4; ++c1) {
     uint2 o[4];
     kmer_extend(v, mid[c1], o);
     const uint64_t p = (uint64_t)c1 * grand + g;  // the child's number among the strings of K - 1 bases
 #pragma unroll
-    for (uint32_t c = 0; c < 4; ++c) {
-      uint32_t second = (o[c].y > o[c].x && o[c].x <= v.n) ? sa[o[c].x] : 0u;
-      if (sizebits) {
-        const uint32_t size = o[c].y > o[c].x ? o[c].y - o[c].x : 0u;
-        second |= (size < cap ? size : cap) << (32u - sizebits);
-      }
-      entries[(uint64_t)c * 4 * grand + p] = make_uint2(o[c].x, second);
-    }
+    for (uint32_t c = 0; c < 4; ++c)
+      entries[(uint64_t)c * 4 * grand + p] = make_uint2(o[c].x, kmer_second_word(v, o[c], sa, sizebits));
   }
 }
 

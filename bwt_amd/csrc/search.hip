@@ -172,7 +172,20 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
       ep = e_ep;
       word = w0;
       i = (int)a - 1;
-      if (e_ep - e_sp == 1) table_pos = e_pos;  // the one occurrence of the string: SA[sp] without the lookup
+      if (e_ep - e_sp == 1) {
+        table_pos = e_pos;  // the one occurrence of the string: SA[sp] without the lookup
+      } else if (VERIFY && i >= 0 && v.kmer_w == 2) {
+        // a few rows, and the entry holds their BWT symbols: if exactly one row goes on with the
+        // read's next base, the search is down to that row's suffix without a rank query, and the
+        // comparison with the text in front of it (which begins with that base) decides the rest
+        const uint32_t wi = (uint32_t)i >> 4;
+        const uint32_t cw = wi == wa ? w0 : word_at(wi);
+        const uint32_t rows = kmer_rows_with(e_pos, e_ep - e_sp, v.kmer_sizebits, (cw >> (2 * (i & 15))) & 3u);
+        if (rows && !(rows & (rows - 1u))) {
+          sp = e_sp + (uint32_t)__builtin_ctz(rows) / 2u;
+          ep = sp + 1;
+        }
+      }
     }
   }
   if (i == -2) {  // no table, a short read, or a string the text does not hold: step by step

@@ -77,6 +77,10 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 os.environ["BWT_MI355X_KMER"] = str(k_env)
             else:
                 os.environ.pop("BWT_MI355X_KMER", None)
+            if rng.integers(0, 3) == 0:  # fewer size bits in table entries (0: the form of texts of 2^30 bases and more)
+                os.environ["BWT_MI355X_KMER_SIZEBITS"] = "0234"[int(rng.integers(0, 4))]
+            else:
+                os.environ.pop("BWT_MI355X_KMER_SIZEBITS", None)
             if rng.integers(0, 3) == 0:
                 os.environ["BWT_MI355X_ISA_TWO_STEP"] = "12"[int(rng.integers(0, 2))]
             else:
@@ -188,9 +192,11 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                         assert got == want[r], f"align {name} anchor={a_len} read {r} len {len(al[r])}: {got[0]} vs {want[r][0]}"
             full.close(); lean.close(); loaded.close()
         except AssertionError as e:
-            raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')}: {e}") from e
+            raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')} "
+                                 f"sizebits_env={os.environ.get('BWT_MI355X_KMER_SIZEBITS')}: {e}") from e
         finally:
             os.environ.pop("BWT_MI355X_KMER", None)
+            os.environ.pop("BWT_MI355X_KMER_SIZEBITS", None)
             os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
         it += 1
         seed += 1
