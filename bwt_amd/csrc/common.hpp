@@ -212,6 +212,11 @@ struct bwtgpu_index {
   // bases starts there.
   uint32_t *d_kmer = nullptr;
   uint32_t kmer_k = 0;
+  // Beside a two-word table: the level two bases up, [start, end) of every string of
+  // kmer_k - 2 bases as the build computed it (no gap list: both ends are stored).  A
+  // read whose last kmer_k bases do not occur starts there instead of at its last base.
+  uint2 *d_kmer2 = nullptr;
+  uint2 *d_kmer4 = nullptr;  // the same four bases up (strings of kmer_k - 4 bases), for when that level has no rows either
   // Words per table entry: 1 = the interval start alone; 2 = the start and, next to it,
   // SA[start] -- the text position of the string when it occurs exactly once (half of
   // all strings of ceil(log4 n) bases that occur at all), which saves such a search the

@@ -14,6 +14,8 @@ struct IndexView {
   const uint32_t *isa;    // PosRecords, 16 words each
   const uint32_t *text2;
   const uint32_t *kmer;   // null unless the index has the k-mer interval table
+  const uint2 *kmer2;     // null, or the intervals of the strings of kmer_k - 2 bases
+  const uint2 *kmer4;     // null, or those of the strings of kmer_k - 4 bases
   uint32_t kmer_k;
   uint32_t kmer_w;        // words per table entry: 1 (start) or 2 (start, SA[start])
   uint32_t kmer_sizebits; // top bits of a two-word entry's second word that hold the interval's size, or 0
@@ -24,7 +26,7 @@ struct IndexView {
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc};
+                   ix->d_kmer,   ix->d_kmer2, ix->d_kmer4, ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {

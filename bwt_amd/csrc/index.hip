@@ -510,7 +510,7 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   static_assert(kKmerMaxGaps >= 15, "one pair per suffix shorter than the longest table string");
   uint64_t entries = 0;
   uint32_t *tab = nullptr;
-  uint2 *tmp_a = nullptr, *tmp_b = nullptr;
+  uint2 *tmp_a = nullptr, *tmp_b = nullptr, *kmer4 = nullptr;
   for (;; --K) {
     entries = 1ull << (2 * K);
     const size_t tab_bytes = (entries * W + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2);
@@ -552,6 +552,16 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
       e = hipGetLastError();
       break;
     }
+    if (W == 2 && K >= 9 && j + 3 == K) {
+      // level K - 4 is about to be overwritten by level K - 2: a copy stays with the index
+      // (a sixteenth of the level that is kept as it is; skipped when there is no room)
+      const size_t bytes = sizeof(uint2) << (2 * (K - 4));
+      if (pool_alloc(&kmer4, bytes) == hipSuccess)
+        e = hipMemcpyAsync(kmer4, buf(j - 1), bytes, hipMemcpyDeviceToDevice, s);
+      else
+        (void)hipGetLastError();
+      if (e != hipSuccess) break;
+    }
     if (j + 1 < K)
       BWT_LAUNCH("kmer_level", k_kmer_level<false>, dim3((unsigned)div_up(parents, 256)), dim3(256), 0, s, v,
                  buf(j), buf(j + 1), (uint32_t *)nullptr, j, (const uint32_t *)nullptr, 0u);
@@ -564,11 +574,17 @@ int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s) {
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) (void)hipDeviceSynchronize();
   pool_free(tmp_a);
-  pool_free(tmp_b);
+  // the level two bases up stays with a two-word table (it was the last pass's input):
+  // where a search finds that the last K bases of a read do not occur, it goes on from there
+  const bool keep_level = e == hipSuccess && W == 2 && K >= 7;
+  if (!keep_level) pool_free(tmp_b);
   if (e != hipSuccess) {
     pool_free(tab);
+    pool_free(kmer4);
     return set_error(kErrHip, "k-mer table build: %s", hipGetErrorString(e));
   }
+  ix->d_kmer2 = keep_level ? tmp_b : nullptr;
+  ix->d_kmer4 = kmer4;
   ix->d_kmer = tab;
   ix->kmer_k = K;
   ix->kmer_w = W;
@@ -677,6 +693,8 @@ void bwtgpu_index_free(bwtgpu_index *ix) {
   pool_free(ix->d_isa);
   pool_free(ix->d_text2);
   pool_free(ix->d_kmer);
+  pool_free(ix->d_kmer2);
+  pool_free(ix->d_kmer4);
   if (cur != ix->device) (void)hipSetDevice(cur);
   delete ix;
 }
@@ -768,7 +786,9 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
          (ix->d_sa ? ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
          (ix->d_isa ? pos_record_count(ix->n) * sizeof(PosRecord) : 0) +
          (ix->d_kmer ? (((uint64_t)ix->kmer_w << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2)
-                     : 0);
+                     : 0) +
+         (ix->d_kmer2 ? (sizeof(uint2) << (2 * (ix->kmer_k - 2))) : 0) +
+         (ix->d_kmer4 ? (sizeof(uint2) << (2 * (ix->kmer_k - 4))) : 0);
 }
 
 int bwtgpu_index_compact(bwtgpu_index *ix) {
@@ -781,9 +801,12 @@ int bwtgpu_index_compact(bwtgpu_index *ix) {
   pool_free(ix->d_isa);
   pool_free(ix->d_text2);
   pool_free(ix->d_kmer);
+  pool_free(ix->d_kmer2);
+  pool_free(ix->d_kmer4);
   pool_release_idle();
   ix->d_sa = ix->d_isa = ix->d_text2 = nullptr;
   ix->d_kmer = nullptr;
+  ix->d_kmer2 = ix->d_kmer4 = nullptr;
   ix->kmer_k = 0;
   ix->want_records = ix->want_kmer = ix->want_recover = false;
   ix->search_ready.store(true, std::memory_order_release);

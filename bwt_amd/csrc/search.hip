@@ -186,6 +186,29 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
           ep = sp + 1;
         }
       }
+    } else if (v.kmer2) {
+      // the last K bases do not occur; if the last K - 2 do, the interval empties on one of the two
+      // bases in front of them, and the steps from that level's interval are the ones loc_search takes
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      const u32x2 iv = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(v.kmer2) +
+                                                  ((x >> (32 - 2 * K)) & ((1u << (2 * (K - 2))) - 1u)));
+      if (COUNT) n_ent += 2;
+      if (iv.y > iv.x) {
+        sp = iv.x;
+        ep = iv.y;
+        i = (int)a + 1;
+        word = (((uint32_t)i >> 4) == wa) ? w0 : w1;
+      } else if (v.kmer4) {  // nor do the last K - 2: the level two bases further up
+        const u32x2 iv4 = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(v.kmer4) +
+                                                     ((x >> (32 - 2 * K)) & ((1u << (2 * (K - 4))) - 1u)));
+        if (COUNT) n_ent += 2;
+        if (iv4.y > iv4.x) {
+          sp = iv4.x;
+          ep = iv4.y;
+          i = (int)a + 3;
+          word = (((uint32_t)i >> 4) == wa) ? w0 : w1;
+        }
+      }
     }
   }
   if (i == -2) {  // no table, a short read, or a string the text does not hold: step by step
