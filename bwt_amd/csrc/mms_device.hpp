@@ -114,6 +114,22 @@ __device__ __forceinline__ int mms_dev(const IndexView &v, const CTab &C, const 
         *sp_out = 0;
         *ep_out = 0;
         return 0;
+      } else if (v.kmer2) {
+        // the last K bases do not occur: go on from the interval of the last K - 2 (or K - 4) where
+        // the index keeps those levels of the table, instead of from the last base
+        const uint2 iv = v.kmer2[x & ((1u << (2 * (K - 2))) - 1u)];
+        if (iv.y > iv.x) {
+          start = iv.x;
+          end = iv.y;
+          i = len - K + 1;
+        } else if (v.kmer4) {
+          const uint2 iv4 = v.kmer4[x & ((1u << (2 * (K - 4))) - 1u)];
+          if (iv4.y > iv4.x) {
+            start = iv4.x;
+            end = iv4.y;
+            i = len - K + 3;
+          }
+        }
       }
     }
   }
