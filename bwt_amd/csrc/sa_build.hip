@@ -135,22 +135,26 @@ struct TileInfo {
   uint32_t seg, row0, count;
 };
 
+// one thread's work: which segment a tile lies in and which rows it covers (count 0: no such tile)
+__device__ __forceinline__ void tile_info(uint32_t tile, const Seg *segs, const uint32_t *tile_first,
+                                          const Counters *ctr, TileInfo *out) {
+  if (tile >= ctr->total_tiles) {
+    out->count = 0;
+    return;
+  }
+  const uint32_t s = find_segment(tile_first, ctr->ncur, tile);
+  const Seg sg = segs[s];
+  const uint32_t off = (tile - tile_first[s]) * (uint32_t)kPartTile;
+  out->seg = s;
+  out->row0 = sg.start + off;
+  const uint32_t left = sg.size - off;
+  out->count = left < (uint32_t)kPartTile ? left : (uint32_t)kPartTile;
+}
+
 __device__ __forceinline__ bool locate_tile_at(uint32_t tile, const Seg *segs,
                                                const uint32_t *tile_first, const Counters *ctr,
                                                TileInfo *sh) {
-  if (threadIdx.x == 0) {
-    if (tile >= ctr->total_tiles) {
-      sh->count = 0;
-    } else {
-      const uint32_t s = find_segment(tile_first, ctr->ncur, tile);
-      const Seg sg = segs[s];
-      const uint32_t off = (tile - tile_first[s]) * (uint32_t)kPartTile;
-      sh->seg = s;
-      sh->row0 = sg.start + off;
-      const uint32_t left = sg.size - off;
-      sh->count = left < (uint32_t)kPartTile ? left : (uint32_t)kPartTile;
-    }
-  }
+  if (threadIdx.x == 0) tile_info(tile, segs, tile_first, ctr, sh);
   __syncthreads();
   return sh->count != 0;
 }
@@ -184,12 +188,16 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
             const uint32_t *__restrict__ tile_first, uint32_t depth,
             const Counters *__restrict__ ctr, uint32_t *__restrict__ seg_counts) {
   __shared__ uint32_t hist[256];
-  __shared__ TileInfo ti;
+  __shared__ TileInfo tis[kHistTilesPerGroup];
   hist[threadIdx.x] = 0;
+  // the group's tiles are looked up side by side: a look-up is a chain of a dozen dependent loads
+  if (threadIdx.x < kHistTilesPerGroup)
+    tile_info(blockIdx.x * kHistTilesPerGroup + threadIdx.x, segs, tile_first, ctr, &tis[threadIdx.x]);
+  __syncthreads();
   uint32_t cur_seg = 0xFFFFFFFFu;
   for (uint32_t k = 0; k < kHistTilesPerGroup; ++k) {
-    const uint32_t tile = blockIdx.x * kHistTilesPerGroup + k;
-    const bool live = locate_tile_at(tile, segs, tile_first, ctr, &ti);
+    const TileInfo ti = tis[k];
+    const bool live = ti.count != 0;
     const uint32_t seg = live ? ti.seg : 0xFFFFFFFFu;
     if (seg != cur_seg) {
       if (cur_seg != 0xFFFFFFFFu) {
@@ -202,19 +210,39 @@ k_part_hist(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src,
     }
     if (!live) break;
     const uint32_t row0 = ti.row0, count = ti.count;
-#pragma unroll 4
-    for (int i = 0; i < kHistItems; ++i) {
-      const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
-      if (j < count) {
-        uint32_t d;
-        if (MODE == 2) {
-          d = (srckey[row0 + j] >> 16) & 255u;
-        } else if (MODE == 3) {
-          d = srckey[row0 + j] >> 24;
-        } else {
-          d = key32(tb, (uint64_t)src[row0 + j] + depth) >> 24;
+    if (MODE == 2 || MODE == 3) {
+      // the digit comes with the row: the tile's words are read four to a load where they are aligned
+      auto add = [&](uint32_t w) { atomicAdd(&hist[MODE == 2 ? (w >> 16) & 255u : w >> 24], 1u); };
+      const uint32_t *p = srckey + row0;
+      uint32_t head = (4u - (row0 & 3u)) & 3u;
+      head = head < count ? head : count;
+      if (threadIdx.x < head) add(p[threadIdx.x]);
+      const uint4 *pv = reinterpret_cast<const uint4 *>(p + head);
+      const uint32_t nv = (count - head) / 4u;
+      constexpr int kVecs = kPartTile / 4 / kPartThreads;  // per thread in a full tile
+      uint4 q[kVecs];
+#pragma unroll
+      for (int u = 0; u < kVecs; ++u) {
+        const uint32_t i = (uint32_t)u * kPartThreads + threadIdx.x;
+        q[u] = i < nv ? pv[i] : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < kVecs; ++u) {
+        const uint32_t i = (uint32_t)u * kPartThreads + threadIdx.x;
+        if (i < nv) {
+          add(q[u].x);
+          add(q[u].y);
+          add(q[u].z);
+          add(q[u].w);
         }
-        atomicAdd(&hist[d], 1u);
+      }
+      const uint32_t done = head + 4u * nv;
+      if (done + threadIdx.x < count) add(p[done + threadIdx.x]);
+    } else {
+#pragma unroll 4
+      for (int i = 0; i < kHistItems; ++i) {
+        const uint32_t j = (uint32_t)i * kPartThreads + threadIdx.x;
+        if (j < count) atomicAdd(&hist[key32(tb, (uint64_t)src[row0 + j] + depth) >> 24], 1u);
       }
     }
     __syncthreads();
@@ -449,13 +477,47 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   if (!locate_tile(segs, tile_first, ctr, &ti)) return;
   const uint32_t row0 = ti.row0, count = ti.count;
-  uint32_t id[kScat1Items], key[kScat1Items];
+  // The order of a tile's rows is free, so a thread takes four neighbouring rows per load where the
+  // rows are 16-byte aligned (4-byte loads, one row per lane, kept the kernel's loads in flight a
+  // quarter as deep); the up to three rows in front of the first aligned one and behind the last whole
+  // group of four are a ninth item of the first threads.
+  constexpr int kVecs = kScat1Items / 4;
+  static_assert(kScat1Items % 4 == 0, "whole groups of four rows per thread");
+  uint32_t id[kScat1Items + 1], key[kScat1Items + 1];
+  uint32_t have = 0;  // bit i: item i holds a row
+  uint32_t head = (4u - (row0 & 3u)) & 3u;
+  head = head < count ? head : count;
+  const uint32_t nv = (count - head) / 4u, done = head + 4u * nv;
+  {
+    const uint4 *sv = reinterpret_cast<const uint4 *>(src + row0 + head);
+    const uint4 *kvv = reinterpret_cast<const uint4 *>(srckey + row0 + head);
+    uint4 a[kVecs], b[kVecs];
 #pragma unroll
-  for (int i = 0; i < kScat1Items; ++i) {
-    const uint32_t j = (uint32_t)i * kScat1Threads + t;
-    if (j < count) {
-      id[i] = src[row0 + j];
-      const uint32_t old = srckey[row0 + j];
+    for (int u = 0; u < kVecs; ++u) {
+      const uint32_t i = (uint32_t)u * kScat1Threads + t;
+      if (i < nv) {
+        a[u] = sv[i];
+        b[u] = kvv[i];
+        have |= 15u << (4 * u);
+      }
+    }
+    // odd rows: t < head takes row t, the next threads the rows from `done` on
+    const uint32_t odd = t < head ? t : done + (t - head);
+    if (odd < count && (t < head || odd >= done)) {
+      id[kScat1Items] = src[row0 + odd];
+      key[kScat1Items] = srckey[row0 + odd];
+      have |= 1u << kScat1Items;
+    }
+#pragma unroll
+    for (int u = 0; u < kVecs; ++u) {
+      id[4 * u] = a[u].x, id[4 * u + 1] = a[u].y, id[4 * u + 2] = a[u].z, id[4 * u + 3] = a[u].w;
+      key[4 * u] = b[u].x, key[4 * u + 1] = b[u].y, key[4 * u + 2] = b[u].z, key[4 * u + 3] = b[u].w;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i <= kScat1Items; ++i) {
+    if ((have >> i) & 1u) {
+      const uint32_t old = key[i];
       const uint32_t d = top_digit ? old >> 24 : (old >> 16) & 255u;
       atomicAdd(&hist[d], 1u);
       if (gather_all)
@@ -488,8 +550,8 @@ k_part_scatter(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ src
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < kScat1Items; ++i) {
-    if ((uint32_t)i * kScat1Threads + t < count) {
+  for (int i = 0; i <= kScat1Items; ++i) {
+    if ((have >> i) & 1u) {
       const uint32_t d = key[i] >> 24;
       const uint32_t p = lstart[d] + atomicAdd(&fill[d], 1u);
       ids[p] = id[i];
