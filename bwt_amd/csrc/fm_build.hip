@@ -155,16 +155,40 @@ k_isa_deal(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ in, uin
     fill[t] = 0;
   }
   __syncthreads();
+  // a thread's items are neighbours in memory, 16 bytes to a load: four rows of the suffix array
+  // (level 1) or two pairs (level 2); which item goes to which thread is free
+  constexpr int kPer = LEVEL == 1 ? 4 : 2;
+  static_assert(kIsaItems % kPer == 0, "whole loads per thread");
+  auto item_row = [&](int i) {
+    return row0 + (uint64_t)kPer * ((uint64_t)(i / kPer) * kIsaThreads + t) + (uint64_t)(i % kPer);
+  };
   uint64_t pr[kIsaItems];
 #pragma unroll
-  for (int i = 0; i < kIsaItems; ++i) {
-    const uint64_t j = row0 + (uint64_t)i * kIsaThreads + t;
-    pr[i] = 0;
-    if (j < rows) {
-      pr[i] = LEVEL == 1 ? ((uint64_t)j << 32) | sa[j] : in[j];
-      atomicAdd(&hist[((uint32_t)pr[i] >> shift) & 255u], 1u);
+  for (int u = 0; u < kIsaItems / kPer; ++u) {
+    const uint64_t j0 = item_row(kPer * u);
+    if (j0 + kPer <= rows) {
+      if (LEVEL == 1) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(sa + j0);
+        pr[4 * u] = (j0 << 32) | q.x;
+        pr[4 * u + 1] = ((j0 + 1) << 32) | q.y;
+        pr[4 * u + 2] = ((j0 + 2) << 32) | q.z;
+        pr[4 * u + 3] = ((j0 + 3) << 32) | q.w;
+      } else {
+        const uint4 q = *reinterpret_cast<const uint4 *>(in + j0);
+        pr[2 * u] = ((uint64_t)q.y << 32) | q.x;
+        pr[2 * u + 1] = ((uint64_t)q.w << 32) | q.z;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < kPer; ++e) {
+        const uint64_t j = j0 + e;
+        pr[kPer * u + e] = j < rows ? (LEVEL == 1 ? (j << 32) | sa[j] : in[j]) : 0ull;
+      }
     }
   }
+#pragma unroll
+  for (int i = 0; i < kIsaItems; ++i)
+    if (item_row(i) < rows) atomicAdd(&hist[((uint32_t)pr[i] >> shift) & 255u], 1u);
   __syncthreads();
   uint32_t c = 0, v = 0;
   if (t < 256) {
@@ -186,8 +210,7 @@ k_isa_deal(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ in, uin
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < kIsaItems; ++i) {
-    const uint64_t j = row0 + (uint64_t)i * kIsaThreads + t;
-    if (j < rows) {
+    if (item_row(i) < rows) {
       const uint32_t b = ((uint32_t)pr[i] >> shift) & 255u;
       stage[lstart[b] + atomicAdd(&fill[b], 1u)] = pr[i];
     }
