@@ -172,3 +172,34 @@ def test_3100_mbp_index_and_search(gpu):
     assert torch.equal(pos2, pos[:2_000_000])
     ix.close()
     gpu._lib.load().bwtgpu_release_cache()  # 66 GB of workspace: back to the driver for the tests that follow
+
+
+def test_largest_text_the_32_bit_rows_allow(gpu):
+    """4.294 Gbp, just under 2^32 rows (lengths, rows and positions are the reference's 4-byte
+    fields read as unsigned, seqindex.h:14-22): the index certified on the device, reads cut
+    from the text found and located at their offsets by the one-call form, the two-call form
+    and the rank blocks alone giving the same answers."""
+    n, R, m = 4_294_000_000, 10_000_000, 100
+    d_text = gpu.gen_genome(n, synth.GENOME_SEED)
+    ix = gpu.build_index_dev(d_text, n)
+    assert ix.C[0] == 1 and ix.C[4] == n + 1 and 0 < ix.endloc <= n
+    rep = ix.certify(d_text)
+    assert all(v == 0 for v in rep.values()), rep
+    gpu._lib.load().bwtgpu_release_cache()
+    reads, offs = gpu.gen_reads(d_text, n, R, m, synth.READS_SEED)
+    sp, ep, pos = ix.search_locate(reads, m, R)
+    spn, epn, offn, posn = (gpu.to_numpy_u32(x) for x in (sp, ep, offs, pos))
+    cut = offn != 0xFFFFFFFF
+    assert np.all(epn[cut] > spn[cut])
+    unique = cut & (epn - spn == 1)
+    assert unique.mean() > 0.9
+    np.testing.assert_array_equal(posn[unique], offn[unique])
+    a, b, lr = ix.search(reads, m, R, want_locrow=True)
+    assert torch.equal(a, sp) and torch.equal(b, ep) and torch.equal(ix.locate_rows(lr), pos)
+    ix.compact()
+    k = 1_000_000
+    a, b, lr = ix.search(reads[: k * m], m, k, want_locrow=True)
+    assert torch.equal(a, sp[:k]) and torch.equal(b, ep[:k]) and torch.equal(ix.locate_rows(lr), pos[:k])
+    ix.close()
+    gpu._lib.load().bwtgpu_release_cache()
+
