@@ -650,6 +650,19 @@ int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride
   return 0; /* 0xFFFFFFFF reads as -1 */
 }
 
+int fmi_search_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                            int *sp, int *ep, int *pos) {
+  bwtgpu_index *ix = device_index(fmi);
+  if (!ix) return -1;
+  /* one pass over the reads: an index with position records has the positions by the time it has the intervals */
+  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
+                         (uint32_t *)sp, (uint32_t *)ep, NULL, (uint32_t *)pos)) {
+    report("search and locate");
+    return -1;
+  }
+  return 0;
+}
+
 void fmi_pack_reads(const char *pats, int len, long stride, long nreads, unsigned *words) {
   /* host threads only: no device is needed to pack */
   if (bwtgpu_pack_reads_host((const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads, words))

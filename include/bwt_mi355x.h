@@ -99,6 +99,10 @@ int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, lon
 /* locate per read: position, or -1 */
 int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride,
                      long nreads, int *pos);
+/* loc_search and locate of every read in one pass over the reads (what filetest.c and the
+ * worker loop fmitest.c:54-65 do per read): sp[r], ep[r], pos[r]; any of the three may be NULL */
+int fmi_search_locate_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                            long nreads, int *sp, int *ep, int *pos);
 /* Reads packed to 2 bits per base, for callers that hold many of them: read r
  * becomes the (len+15)/16 unsigned words at words + r * ((len+15)/16), base k at
  * bits 2 (k % 16) of word k / 16.  fmi_search_batch_packed = loc_search, and

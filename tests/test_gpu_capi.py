@@ -53,6 +53,7 @@ def capi(gpu):
     L.fmi_search_batch.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, i32p, i32p]
     L.fmi_reverse_search_batch.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, i32p]
     L.fmi_locate_batch.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, i32p]
+    L.fmi_search_locate_batch.argtypes = [fp, u8p, C.c_int, C.c_long, C.c_long, i32p, i32p, i32p]
     L.fmi_unc_sa_batch.argtypes = [fp, i32p, C.c_long, i32p]
     libc = C.CDLL(None)
     libc.fopen.restype = C.c_void_p
@@ -192,6 +193,9 @@ def test_batch_forms_and_index_file(capi, oracle, tmp_path):
     pos = np.zeros(R, np.int32)
     assert capi.fmi_locate_batch(fmi, _p(reads), m, m, R, _p(pos, i32p)) == 0
     assert sha(np.where(ep - sp == 1, pos, -2).astype(np.int32)) == rec["locate_unique"]
+    sp2, ep2, pos2 = (np.zeros(R, np.int32) for _ in range(3))
+    assert capi.fmi_search_locate_batch(fmi, _p(reads), m, m, R, _p(sp2, i32p), _p(ep2, i32p), _p(pos2, i32p)) == 0
+    assert (sp2 == sp).all() and (ep2 == ep).all() and (pos2 == pos).all()
     rows = (np.arange(rec["probe_rows"], dtype=np.int32) * rec["probe_rows_step"])
     out = np.zeros(len(rows), np.int32)
     assert capi.fmi_unc_sa_batch(fmi, _p(rows, i32p), len(rows), _p(out, i32p)) == 0
