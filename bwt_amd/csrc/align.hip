@@ -61,7 +61,11 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
   // nw_fast / sw_fast of read bases pat[p0 + i * pstep], i < len1, against genome
   // bases g0 + j * gstep, j < len2, onto the stack
   auto dp = [&](int p0, int pstep, int len1, int64_t g0, int gstep, int len2, int mode) -> int {
-    if (n_ops + (uint32_t)(len1 + len2) > cap) {
+    // nw_fast returns at once for an empty read piece (smw.c:28-30), whatever the genome piece: the
+    // first anchor of a read has no tail, and its genome piece can come out negative when the anchor's
+    // length counts trailing Ns that mms skipped past the end of the text
+    if (mode == 0 && len1 == 0) return 0;
+    if (len2 < 0 || n_ops + (uint32_t)(len1 + len2) > cap) {
       overflow = true;
       return 0;
     }
@@ -153,6 +157,7 @@ k_align_reads(IndexView v, CTab C, const uint8_t *__restrict__ text, const uint8
     len -= anchlen;
     anchmisses -= anchlen / 10;
     n_ops = 0;  // :279
+    overflow = false;  // what did not fit went with the rest of the abandoned attempt
   }
   if (!done) {
     if (len > nmisses || nmisses < 1) {  // :281-283

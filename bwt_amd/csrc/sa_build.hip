@@ -1654,6 +1654,29 @@ __device__ __forceinline__ bool dbl_locate_tile(uint32_t tile, const Seg *segs, 
   return sh->count != 0;
 }
 
+// f(value, valid) for every row of a[row0 .. row0 + count), in no particular order, every thread of the
+// workgroup calling f the same number of times (f may be wave-wide): the rows are read four to a load where
+// they are 16-byte aligned, the up to three rows in front and behind one per thread.
+template <typename F>
+__device__ __forceinline__ void dbl_each_row(const uint32_t *__restrict__ a, uint32_t row0, uint32_t count, F f) {
+  const uint32_t t = threadIdx.x;
+  uint32_t head = (4u - (row0 & 3u)) & 3u;
+  head = head < count ? head : count;
+  if (head) f(t < head ? a[row0 + t] : 0u, t < head);
+  const uint4 *av = reinterpret_cast<const uint4 *>(a + row0 + head);
+  const uint32_t nv = (count - head) / 4u;
+  for (uint32_t i0 = 0; i0 < nv; i0 += kDblPartThreads) {
+    const bool valid = i0 + t < nv;
+    const uint4 q = valid ? av[i0 + t] : make_uint4(0, 0, 0, 0);
+    f(q.x, valid);
+    f(q.y, valid);
+    f(q.z, valid);
+    f(q.w, valid);
+  }
+  const uint32_t done = head + 4u * nv;
+  if (done < count) f(done + t < count ? a[row0 + done + t] : 0u, done + t < count);
+}
+
 __global__ void __launch_bounds__(kDblPartThreads)
 k_dbl_minmax(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first, uint32_t nsegs,
              const DblCtr *__restrict__ ctr, const uint32_t *__restrict__ key, uint32_t *__restrict__ mm) {
@@ -1665,17 +1688,12 @@ k_dbl_minmax(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fir
   }
   if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
   uint32_t a = 0xFFFFFFFFu, b = 0;
-  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
-#pragma unroll
-    for (uint32_t i = 0; i < kDblItems; ++i) {
-      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
-      if (k < ti.count) {
-        const uint32_t v = key[ti.row0 + k];
-        a = v < a ? v : a;
-        b = v > b ? v : b;
-      }
+  dbl_each_row(key, ti.row0, ti.count, [&](uint32_t v, bool valid) {
+    if (valid) {
+      a = v < a ? v : a;
+      b = v > b ? v : b;
     }
-  }
+  });
   for (int off = 32; off; off >>= 1) {
     const uint32_t x = __shfl_xor(a, off, 64), y = __shfl_xor(b, off, 64);
     a = x < a ? x : a;
@@ -1733,15 +1751,9 @@ k_dbl_hist(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_first
   const uint32_t lo = mm[2 * ti.seg], hi = mm[2 * ti.seg + 1];
   if (lo >= hi) return;  // one key: the group stays as it is this round
   const float scale = dbl_scale(lo, hi);
-  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
-#pragma unroll
-    for (uint32_t i = 0; i < kDblItems; ++i) {
-      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
-      const bool valid = k < ti.count;
-      const uint32_t d = valid ? dbl_digit(key[ti.row0 + k], lo, scale) : 0u;
-      dbl_count(hist, d, valid, threadIdx.x & 63u);
-    }
-  }
+  dbl_each_row(key, ti.row0, ti.count, [&](uint32_t v, bool valid) {
+    dbl_count(hist, valid ? dbl_digit(v, lo, scale) : 0u, valid, threadIdx.x & 63u);
+  });
   __syncthreads();
   if (threadIdx.x < 256) {
     const uint32_t c = hist[threadIdx.x];
@@ -1812,15 +1824,9 @@ k_dbl_scatter(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_fi
   const uint32_t row0 = ti.row0, count = ti.count;
   const uint32_t old_label = glabel_old[ti.seg];
   const uint32_t lane = t & 63u, wave = t >> 6;
-  for (uint32_t c0 = 0; c0 < count; c0 += kDblChunk) {
-#pragma unroll
-    for (uint32_t i = 0; i < kDblItems; ++i) {
-      const uint32_t j = c0 + i * kDblPartThreads + t;
-      const bool valid = j < count;
-      const uint32_t d = valid ? dbl_digit(key[row0 + j], lo, scale) : 0u;
-      dbl_count(hist, d, valid, lane);
-    }
-  }
+  dbl_each_row(key, row0, count, [&](uint32_t v, bool valid) {
+    dbl_count(hist, valid ? dbl_digit(v, lo, scale) : 0u, valid, lane);
+  });
   __syncthreads();
   if (bin) {
     const uint32_t c = hist[t];
@@ -1900,15 +1906,22 @@ k_dbl_copyback(const Seg *__restrict__ segs, const uint32_t *__restrict__ tile_f
   __shared__ TileInfo ti;
   if (!dbl_locate_tile(blockIdx.x, segs, tile_first, nsegs, ctr, &ti)) return;
   if (mm[2 * ti.seg] >= mm[2 * ti.seg + 1]) return;
-  for (uint32_t c0 = 0; c0 < ti.count; c0 += kDblChunk) {
-#pragma unroll
-    for (uint32_t i = 0; i < kDblItems; ++i) {
-      const uint32_t k = c0 + i * kDblPartThreads + threadIdx.x;
-      if (k < ti.count) {
-        sa[ti.row0 + k] = src_sa[ti.row0 + k];
-        key[ti.row0 + k] = src_key[ti.row0 + k];
-      }
-    }
+  // 16 bytes a lane over the aligned middle of the rows, the few rows in front and behind one per thread
+  const uint32_t t = threadIdx.x, row0 = ti.row0, count = ti.count;
+  uint32_t head = (4u - (row0 & 3u)) & 3u;
+  head = head < count ? head : count;
+  const uint32_t nv = (count - head) / 4u, done = head + 4u * nv;
+  const uint32_t odd = t < head ? t : done + (t - head);
+  if (odd < count && (t < head || odd >= done)) {
+    sa[row0 + odd] = src_sa[row0 + odd];
+    key[row0 + odd] = src_key[row0 + odd];
+  }
+  const uint4 *ssa = reinterpret_cast<const uint4 *>(src_sa + row0 + head);
+  const uint4 *skey = reinterpret_cast<const uint4 *>(src_key + row0 + head);
+  uint4 *dsa = reinterpret_cast<uint4 *>(sa + row0 + head), *dkey = reinterpret_cast<uint4 *>(key + row0 + head);
+  for (uint32_t i = t; i < nv; i += kDblPartThreads) {
+    dsa[i] = ssa[i];
+    dkey[i] = skey[i];
   }
 }
 

@@ -88,6 +88,32 @@ def test_gpu_align_more_texts_and_lengths(oracle, gpu, n, lo, hi, anchor):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("anchor", [12, 20])
+def test_gpu_align_anchor_at_the_end_of_the_text_with_trailing_ns(oracle, gpu, anchor):
+    """mms skips trailing Ns and counts them (seqindex.c:317-320): an anchor on the last bases of
+    the text then reaches past its end, the genome piece of the (empty) tail comes out negative
+    (single_align.c:196-198), and nw_fast returns at once for the empty read piece (smw.c:28-30)."""
+    n = 460
+    text = oracle.gen_genome(n, 77)
+    bases = synth.unpack(text, n)
+    fo = oracle.make_fmi(text, n)
+    reads = []
+    for tail_ns in (1, 2, 3, 5):
+        for body in (24, 30, 37, 60):
+            for cut in (0, 1, 4):  # the copy ends `cut` bases before the end of the text
+                rd = np.concatenate([bases[n - cut - body: n - cut], np.full(tail_ns, 5, np.uint8)])
+                reads.append(rd.astype(np.uint8))
+                edited = rd.copy()
+                edited[3] = (edited[3] + 1) & 3
+                reads.append(edited.astype(np.uint8))
+    want = [oracle.align_read_anchored(fo, text, rd, anchor) for rd in reads]
+    for ix in (gpu.build_index(text, n), gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=True)):
+        got = _gpu_align(gpu, ix, text, reads, anchor, 80)
+        for rd, g, w in zip(reads, got, want):
+            assert g == w, (len(rd), bytes(rd[-8:]).hex())
+
+
+@pytest.mark.gpu
 def test_gpu_align_marks_reads_it_was_not_sized_for(oracle, gpu):
     n = 20000
     text = oracle.gen_genome(n, 5)

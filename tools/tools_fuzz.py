@@ -189,7 +189,9 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                     for r in range(len(al)):
                         o = 5 * int(offs[r]) + 64 * r
                         got = (int(pos_h[r]), ops_h[o:o + int(nops_h[r])].tobytes())
-                        assert got == want[r], f"align {name} anchor={a_len} read {r} len {len(al[r])}: {got[0]} vs {want[r][0]}"
+                        assert got == want[r], (f"align {name} anchor={a_len} read {r} len {len(al[r])}: {got[0]} vs {want[r][0]}; "
+                                                f"ops ({len(got[1])}) {got[1][:120].hex()} vs ({len(want[r][1])}) {want[r][1][:120].hex()}; "
+                                                f"read {bytes(al[r]).hex()}")
             full.close(); lean.close(); loaded.close()
         except AssertionError as e:
             raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')} "
