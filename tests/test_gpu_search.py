@@ -297,6 +297,54 @@ def test_kmer_table_start_gives_the_same_intervals(oracle, gpu, k, monkeypatch):
     assert loads["kmer_entries"] == (3000 if k >= 2 else 0)
 
 
+@pytest.mark.parametrize("k,sizebits", [(7, None), (9, None), (9, "0"), (11, "2")])
+def test_kmer_table_entry_whose_rows_include_the_dollar_row(oracle, gpu, k, sizebits, monkeypatch):
+    """A table entry of a few rows keeps their BWT symbols, except when the row of suffix 0 is among
+    them (it has no symbol): reads that end in the text's first k bases, where those occur more than
+    once, and reads that end in the other strings of a few rows, against loc_search and locate."""
+    n = 120000
+    rng = np.random.default_rng(5 * k)
+    bases = rng.integers(0, 4, n).astype(np.uint8)
+    # the first k bases occur twice more, once behind each possible base
+    for at, before in ((30000, 1), (70000, 2)):
+        bases[at:at + k] = bases[:k]
+        bases[at - 1] = before
+    text = synth.pack(bases)
+    fo = oracle.make_fmi(text, n)
+    monkeypatch.setenv("BWT_MI355X_KMER", str(k))
+    if sizebits is not None:
+        monkeypatch.setenv("BWT_MI355X_KMER_SIZEBITS", sizebits)
+    full = gpu.build_index(text, n)
+    full.prepare_search()
+    monkeypatch.delenv("BWT_MI355X_KMER")
+    monkeypatch.delenv("BWT_MI355X_KMER_SIZEBITS", raising=False)
+    assert full.kmer_table == (k, 2)
+    m = k + 25
+    reads = []
+    for at in (30000, 70000):
+        reads.append(bases[at + k - m: at + k].copy())          # occurs: ends in the string, one row goes on
+        for c in range(4):                                       # every base in front of the string
+            rd = np.concatenate([rng.integers(0, 4, m - k - 1), [c], bases[:k]]).astype(np.uint8)
+            reads.append(rd)
+    reads.append(np.concatenate([rng.integers(0, 4, m - k), bases[:k]]).astype(np.uint8))
+    reads.append(bases[:k].copy()[-k:].repeat(1))                # the string itself is too short for m: padded below
+    reads[-1] = np.concatenate([rng.integers(0, 4, m - k), reads[-1]]).astype(np.uint8)
+    # and reads cut all over the text (strings of one, a few and many rows)
+    for j in rng.integers(0, n - m, 3000):
+        reads.append(bases[j:j + m].copy())
+    reads = np.stack(reads)
+    R = len(reads)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    want = np.array([oracle.locate(fo, reads[r]) for r in range(R)], np.int64)
+    d = torch.from_numpy(reads.reshape(-1)).cuda()
+    sp, ep, pos = (gpu.to_numpy_u32(x) for x in full.search_locate(d, m, R))
+    np.testing.assert_array_equal(sp, sp_o)
+    np.testing.assert_array_equal(ep, ep_o)
+    got = pos.astype(np.int64)
+    got[got == 0xFFFFFFFF] = -1
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("tail", ["CAAA", "TTTT", "GATTACA", "AAAAAAAA", "ACGT"])
 @pytest.mark.parametrize("k", [2, 3, 5, 6])
 def test_kmer_table_around_the_short_suffixes(oracle, gpu, k, tail, monkeypatch):
