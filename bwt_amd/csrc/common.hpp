@@ -243,6 +243,13 @@ struct bwtgpu_index {
   bool want_recover = false;
   mutable std::atomic<bool> search_ready{true};  // nothing left for index_prepare_search to do
   mutable std::mutex prepare_mu;
+  // Entry points that neither take prepare_mu nor wait for the search-only arrays
+  // (bwtgpu_search_static, bwtgpu_locate_rows) may run while another thread is
+  // making those arrays.  The rule that keeps them safe: an array's pointer is
+  // stored in the index only when the array is complete and the stream that
+  // filled it has been waited for (bwtgpu::publish), and such readers take their
+  // view with view_published (fm_device.hpp), which hands out the search-only
+  // arrays only once search_ready says that all of them are in place.
 };
 
 namespace bwtgpu {
@@ -250,6 +257,9 @@ namespace bwtgpu {
 constexpr int kWave = 64;
 
 inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+// Stores a finished array's pointer in the index (see bwtgpu_index::prepare_mu).
+template <class T>
+inline void publish(T *&slot, T *value) { __atomic_store_n(&slot, value, __ATOMIC_RELEASE); }
 inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
 // search.hip: resolves, once per device and with that device current, the

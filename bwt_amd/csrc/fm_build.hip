@@ -530,9 +530,9 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
 int index_build_records(bwtgpu_index *ix, hipStream_t s) {
   if (!ix->d_sa || !ix->d_text2 || ix->d_isa) return kOk;
   const uint32_t n = ix->n;
-  if (pool_alloc(&ix->d_isa, pos_record_count(n) * sizeof(PosRecord)) != hipSuccess) {
+  uint32_t *isa = nullptr;  // the index gets it when every record is written
+  if (pool_alloc(&isa, pos_record_count(n) * sizeof(PosRecord)) != hipSuccess) {
     (void)hipGetLastError();
-    ix->d_isa = nullptr;
     return kOk;
   }
   // scratch for the two-step scatter: the calling thread's idle build workspace
@@ -548,14 +548,12 @@ int index_build_records(bwtgpu_index *ix, hipStream_t s) {
     if (pool_alloc(&own, ((size_t)n + 1) * 8 + 2048) == hipSuccess) scratch = own;
     else (void)hipGetLastError();  // the one-step scatter needs none
   }
-  int rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, ix->d_isa, scratch, s);
+  int rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, isa, scratch, s);
   if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "position records failed");
   if (rc != kOk) (void)hipDeviceSynchronize();
   pool_free(own);
-  if (rc != kOk) {
-    pool_free(ix->d_isa);
-    ix->d_isa = nullptr;
-  }
+  if (rc != kOk) pool_free(isa);
+  else publish(ix->d_isa, isa);
   return rc;
 }
 
@@ -733,13 +731,15 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (n > kPosRecordMaxN) return set_error(kErrArg, "text of %u bases is too long to keep beside its index", n);
   std::lock_guard<std::mutex> lock(ix->prepare_mu);
-  hipError_t ea = pool_alloc(&ix->d_sa, rows * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
+  if (ix->d_sa) return kOk;  // another thread attached it meanwhile
+  // in buffers of our own until they are complete and checked (see bwtgpu_index::prepare_mu)
+  uint32_t *sa = nullptr, *text2 = nullptr;
+  hipError_t ea = pool_alloc(&sa, rows * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&text2, t2words * 4);
   auto drop = [&]() {
     (void)hipDeviceSynchronize();
-    pool_free(ix->d_sa);
-    pool_free(ix->d_text2);
-    ix->d_sa = ix->d_text2 = nullptr;
+    pool_free(sa);
+    pool_free(text2);
   };
   if (ea != hipSuccess) {
     (void)hipGetLastError();
@@ -749,7 +749,7 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   const size_t ws_bytes = bwtgpu_sa_workspace_bytes(n);
   std::lock_guard<std::mutex> building(g_cache.busy);
   int rc = cache_reserve(256, ws_bytes);
-  if (rc == kOk) rc = sa_build_impl(d_text, n, ix->d_sa, g_cache.ws, ws_bytes, s, nullptr);
+  if (rc == kOk) rc = sa_build_impl(d_text, n, sa, g_cache.ws, ws_bytes, s, nullptr);
   if (rc == kOk) {
     // the suffix array of this text must give the BWT the index was loaded with
     uint32_t *d_endloc = reinterpret_cast<uint32_t *>(g_cache.small);
@@ -758,10 +758,10 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
     hipError_t e = hipMemsetAsync(d_endloc, 0xFF, 4, s);
     if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 4, s);
     if (e == hipSuccess) {
-      BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, ix->d_sa,
-                 rows, d_endloc);
+      BWT_LAUNCH("find_endloc", k_find_endloc, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, sa, rows,
+                 d_endloc);
       BWT_LAUNCH("check_planes", k_check_planes, dim3((unsigned)div_up(ix->nblocks * 64, 256)), dim3(256), 0, s,
-                 d_text, ix->d_sa, n, d_endloc, ix->d_blocks, ix->nblocks, d_flag);
+                 d_text, sa, n, d_endloc, ix->d_blocks, ix->nblocks, d_flag);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(h, d_endloc, sizeof h, hipMemcpyDeviceToHost, s);
@@ -772,7 +772,7 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
   }
   if (rc == kOk) {
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
-               t2words, ix->d_text2);
+               t2words, text2);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
       rc = set_error(kErrHip, "attaching the text failed");
   }
@@ -780,6 +780,8 @@ int bwtgpu_index_attach_text_dev(bwtgpu_index *ix, const uint8_t *d_text, void *
     drop();
     return rc;
   }
+  ix->d_text2 = text2;
+  publish(ix->d_sa, sa);
   // the position records follow when a search first wants them
   ix->want_records = true;
   ix->search_ready.store(false, std::memory_order_release);

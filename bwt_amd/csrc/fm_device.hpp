@@ -29,6 +29,18 @@ inline IndexView view_of(const bwtgpu_index *ix) {
                    ix->d_kmer,   ix->d_kmer2, ix->d_kmer4, ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc};
 }
 
+// The view for entry points that do not wait for the search-only arrays: all of
+// them once search_ready says so; until then the rank blocks and sampled rows
+// alone (what a build or a load has finished before it returns), plus the suffix
+// array if it has been published -- its pointer is stored only when every row is
+// in place.  The answers are the same on either view.
+inline IndexView view_published(const bwtgpu_index *ix) {
+  if (ix->search_ready.load(std::memory_order_acquire)) return view_of(ix);
+  const uint32_t *sa = __atomic_load_n(&ix->d_sa, __ATOMIC_ACQUIRE);
+  return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, sa, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   0u, 1u, 0u, ix->nsym, ix->n, ix->endloc};
+}
+
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
   // r in [0, 63]
   return (1ull << r) - 1ull;

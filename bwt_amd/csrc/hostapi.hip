@@ -235,7 +235,7 @@ int bwtgpu_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, uint32_t m
         CTab C;
         for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
         BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, box.stream,
-                   view_of(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
+                   view_published(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
                    h_pos ? d_out + 3 * kBoxReads : nullptr);
         BWT_CHECK_LAUNCH();
       } else {
@@ -305,7 +305,7 @@ int bwtgpu_reverse_search_host(const bwtgpu_index *ix, const uint8_t *h_pats, ui
         CTab C;
         for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
         BWT_LAUNCH("fm_search_few", k_search_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, box.stream,
-                   view_of(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
+                   view_published(ix), C, box.dev, m, stride, R, d_out, d_out + kBoxReads, d_out + 2 * kBoxReads,
                    (uint32_t *)nullptr);
         BWT_CHECK_LAUNCH();
         BWT_HIP(hipStreamSynchronize(box.stream));

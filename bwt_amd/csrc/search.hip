@@ -650,14 +650,15 @@ int index_recover_arrays(bwtgpu_index *ix, hipStream_t s) {
   if (ix->d_sa || !ix->has_samples) return kOk;
   const uint32_t n = ix->n;
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
+  // filled in buffers of our own: the index gets them when the walks have covered every row
+  uint32_t *sa = nullptr, *text2 = nullptr;
   auto drop = [&] {
-    pool_free(ix->d_sa);
-    pool_free(ix->d_text2);
-    ix->d_sa = ix->d_text2 = nullptr;
+    pool_free(sa);
+    pool_free(text2);
   };
-  hipError_t e = pool_alloc(&ix->d_sa, rows * 4);
-  if (e == hipSuccess) e = pool_alloc(&ix->d_text2, t2words * 4);
-  if (e == hipSuccess) e = hipMemsetAsync(ix->d_text2, 0, t2words * 4, s);
+  hipError_t e = pool_alloc(&sa, rows * 4);
+  if (e == hipSuccess) e = pool_alloc(&text2, t2words * 4);
+  if (e == hipSuccess) e = hipMemsetAsync(text2, 0, t2words * 4, s);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     drop();
@@ -666,9 +667,14 @@ int index_recover_arrays(bwtgpu_index *ix, hipStream_t s) {
   IndexView v = view_of(ix);
   v.sa = nullptr;  // being written
   bool consistent = false;
-  const int rc = chain_walk(v, false, ix->d_idxs, ((uint64_t)n >> kDevSampleShift) + 1, ix->d_sa, ix->d_text2, rows,
-                            &consistent, s);
-  if (rc != kOk || !consistent) drop();  // inconsistent parts: stay on the rank blocks
+  const int rc = chain_walk(v, false, ix->d_idxs, ((uint64_t)n >> kDevSampleShift) + 1, sa, text2, rows,
+                            &consistent, s);  // waits for the stream
+  if (rc != kOk || !consistent) {
+    drop();  // inconsistent parts: stay on the rank blocks
+    return rc;
+  }
+  ix->d_text2 = text2;
+  publish(ix->d_sa, sa);
   return rc;
 }
 
@@ -747,14 +753,14 @@ static uint32_t fused_group_reads(uint32_t m, uint64_t stride, uint64_t R, uint6
 
 // d_pos (optional): the position locate() returns for the read, written by the search
 // kernel itself; only for an index that keeps its position records (ix->d_isa).
-static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
+static int search_impl(const bwtgpu_index *ix, const IndexView &v, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                        uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, uint32_t *d_pos,
                        void *d_ws, size_t ws_bytes, unsigned long long *d_counters, hipStream_t s) {
   if (!ix || !d_pats || !d_sp || !d_ep || !d_ws) return set_error(kErrArg, "null argument");
   if (m == 0 || m > 65535) return set_error(kErrArg, "read length %u out of range [1, 65535]", m);
   if (R == 0) return kOk;
   if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
-  if (d_pos && !ix->d_isa) return set_error(kErrArg, "positions from the search kernel need the position records");
+  if (d_pos && !v.isa) return set_error(kErrArg, "positions from the search kernel need the position records");
   uint64_t fused_lds = 0;
   uint32_t fused_rounds = 1;
   const uint32_t fused_nt = d_counters ? 0u : fused_group_reads(m, stride, R, &fused_lds, &fused_rounds);
@@ -769,12 +775,11 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
   CTable C;
   for (int i = 0; i < 5; ++i) C.c[i] = ix->C[i];
   const dim3 grid((unsigned)div_up(R, 256)), block(256);
-  const IndexView v = view_of(ix);
   // bytes and packed words of a workgroup's reads in LDS: pack inside the search kernel.
   // Long reads get smaller workgroups so that they still fit.
   if (fused_nt) {
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
-    if (ix->d_isa)
+    if (v.isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
                  d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, fused_rounds);
     else
@@ -788,13 +793,13 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
              use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
   BWT_CHECK_LAUNCH();
   if (d_counters) {
-    if (ix->d_isa)
+    if (v.isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
-  } else if (ix->d_isa) {
+  } else if (v.isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
                d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
   } else {
@@ -808,8 +813,9 @@ static int search_impl(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m
 int bwtgpu_search(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
                   uint64_t R, uint32_t *d_sp, uint32_t *d_ep, uint32_t *d_locrow, void *d_ws,
                   size_t ws_bytes, void *stream) {
-  if (ix) BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
-  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_ws, ws_bytes, nullptr,
+  if (!ix) return set_error(kErrArg, "null argument");
+  BWT_TRY(index_ready_for_search(ix, (hipStream_t)stream));
+  return search_impl(ix, view_of(ix), d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_ws, ws_bytes, nullptr,
                      (hipStream_t)stream);
 }
 
@@ -872,7 +878,7 @@ int bwtgpu_search_locate(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
   if (R > (1ull << 40)) return set_error(kErrArg, "too many reads");
   BWT_TRY(index_ready_for_search(ix, s));
   if (ix->d_isa)  // the kernel knows the position of nearly every read by the time it has its interval
-    return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, d_pos, d_ws, ws_bytes, nullptr, s);
+    return search_impl(ix, view_of(ix), d_pats, m, stride, R, d_sp, d_ep, nullptr, d_pos, d_ws, ws_bytes, nullptr, s);
   if (ws_bytes < bwtgpu_search_locate_workspace_bytes(R, m))
     return set_error(kErrWorkspace, "search-and-locate workspace %zu < %zu bytes", ws_bytes,
                      bwtgpu_search_locate_workspace_bytes(R, m));
@@ -880,8 +886,8 @@ int bwtgpu_search_locate(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
     return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
   const size_t sws = bwtgpu_search_workspace_bytes(R, m);
   uint8_t *part = (uint8_t *)d_ws + sws;
-  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, reinterpret_cast<uint32_t *>(part), nullptr, d_ws, sws,
-                      nullptr, s));
+  BWT_TRY(search_impl(ix, view_of(ix), d_pats, m, stride, R, d_sp, d_ep, reinterpret_cast<uint32_t *>(part), nullptr,
+                      d_ws, sws, nullptr, s));
   if (R == 0) return kOk;
   return locate_from_rows(ix, part, R, d_pos, s);
 }
@@ -925,8 +931,9 @@ int bwtgpu_search_static(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t
                      "%llu reads of %u bases need %zu bytes of scratch, bwtgpu_search_static has %zu: "
                      "split the batch or use bwtgpu_search with a workspace",
                      (unsigned long long)R, m, bwtgpu_search_workspace_bytes(R, m), kStaticScratchBytes);
-  return search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_scratch, kStaticScratchBytes, nullptr,
-                     (hipStream_t)stream);
+  // never waits for, and never makes, the search-only arrays: it uses them once all are in place
+  return search_impl(ix, view_published(ix), d_pats, m, stride, R, d_sp, d_ep, d_locrow, nullptr, d_scratch,
+                     kStaticScratchBytes, nullptr, (hipStream_t)stream);
 }
 
 int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_t m, uint64_t stride,
@@ -940,10 +947,11 @@ int bwtgpu_search_profile(const bwtgpu_index *ix, const uint8_t *d_pats, uint32_
                      bwtgpu_search_workspace_bytes(R, m) + 256);
   if (!d_ws || ((uintptr_t)d_ws & 255u)) return set_error(kErrArg, "workspace must be 256-byte aligned");
   unsigned long long *ctr = reinterpret_cast<unsigned long long *>(d_ws);
-  if (ix) BWT_TRY(index_ready_for_search(ix, s));
+  if (!ix) return set_error(kErrArg, "null argument");
+  BWT_TRY(index_ready_for_search(ix, s));
   BWT_HIP(hipMemsetAsync(ctr, 0, 256, s));
-  BWT_TRY(search_impl(ix, d_pats, m, stride, R, d_sp, d_ep, nullptr, nullptr, (uint8_t *)d_ws + 256, ws_bytes - 256, ctr,
-                      s));
+  BWT_TRY(search_impl(ix, view_of(ix), d_pats, m, stride, R, d_sp, d_ep, nullptr, nullptr, (uint8_t *)d_ws + 256,
+                      ws_bytes - 256, ctr, s));
   unsigned long long h[5];
   BWT_HIP(hipMemcpyAsync(h, ctr, sizeof h, hipMemcpyDeviceToHost, s));
   BWT_HIP(hipStreamSynchronize(s));
@@ -962,16 +970,18 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
                      bwtgpu_locate_workspace_bytes());
   if ((uintptr_t)d_ws & 7u) return set_error(kErrArg, "workspace must be 8-byte aligned");
   if (R == 0) return kOk;
-  if (!ix->d_sa && !ix->has_samples)
+  // may run beside another thread's first search on this index: only what has been published
+  const IndexView v = view_published(ix);
+  if (!v.sa && !ix->has_samples)
     return set_error(kErrArg, "this index was loaded without sampled suffix-array rows: it cannot locate");
-  if (ix->d_sa) {
-    BWT_LAUNCH("fm_locate", k_locate_sa, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows,
+  if (v.sa) {
+    BWT_LAUNCH("fm_locate", k_locate_sa, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, v, d_rows,
                R, d_pos);
     BWT_CHECK_LAUNCH();
     return kOk;
   }
   if (R <= kLocateFew && !d_steps) {
-    BWT_LAUNCH("fm_locate", k_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, view_of(ix), d_rows, R,
+    BWT_LAUNCH("fm_locate", k_locate_few, dim3((unsigned)div_up(R, 256)), dim3(256), 0, s, v, d_rows, R,
                d_pos);
     BWT_CHECK_LAUNCH();
     return kOk;
@@ -983,7 +993,7 @@ int bwtgpu_locate_rows(const bwtgpu_index *ix, const uint32_t *d_rows, uint64_t 
   uint64_t waves = div_up(R, (uint64_t)kLocateBatch);
   uint64_t groups = div_up(waves, 4);
   if (groups > 256 * 8) groups = 256 * 8;
-  BWT_LAUNCH("fm_locate", k_locate, dim3((unsigned)groups), dim3(256), 0, s, view_of(ix), d_rows, R,
+  BWT_LAUNCH("fm_locate", k_locate, dim3((unsigned)groups), dim3(256), 0, s, v, d_rows, R,
              d_pos, d_steps, head);
   BWT_CHECK_LAUNCH();
   return kOk;

@@ -215,23 +215,27 @@ int bwtgpu_index_attach_sa(bwtgpu_index *ix, const uint8_t *d_text, const uint32
   BWT_HIP(hipSetDevice(ix->device));
   std::lock_guard<std::mutex> lock(ix->prepare_mu);
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
-  hipError_t ea = pool_alloc(&ix->d_sa, rows * 4);
-  if (ea == hipSuccess) ea = pool_alloc(&ix->d_text2, t2words * 4);
-  if (ea == hipSuccess) ea = hipMemcpyAsync(ix->d_sa, d_sa, rows * 4, hipMemcpyDeviceToDevice, s);
+  if (ix->d_sa) return kOk;  // another thread attached it meanwhile
+  // in buffers of our own until they are complete (see bwtgpu_index::prepare_mu)
+  uint32_t *sa = nullptr, *text2 = nullptr;
+  hipError_t ea = pool_alloc(&sa, rows * 4);
+  if (ea == hipSuccess) ea = pool_alloc(&text2, t2words * 4);
+  if (ea == hipSuccess) ea = hipMemcpyAsync(sa, d_sa, rows * 4, hipMemcpyDeviceToDevice, s);
   if (ea == hipSuccess) {
     BWT_LAUNCH("make_text2", k_text2_words, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
-               t2words, ix->d_text2);
+               t2words, text2);
     ea = hipGetLastError();
   }
   if (ea == hipSuccess) ea = hipStreamSynchronize(s);
   if (ea != hipSuccess) {
     (void)hipGetLastError();
     (void)hipDeviceSynchronize();
-    pool_free(ix->d_sa);
-    pool_free(ix->d_text2);
-    ix->d_sa = ix->d_text2 = nullptr;
+    pool_free(sa);
+    pool_free(text2);
     return set_error(kErrHip, "attaching the suffix array of %u bases: %s", n, hipGetErrorString(ea));
   }
+  ix->d_text2 = text2;
+  publish(ix->d_sa, sa);
   ix->want_records = !ix->d_isa;
   if (ix->want_records) ix->search_ready.store(false, std::memory_order_release);
   return kOk;

@@ -277,6 +277,11 @@ int bwtgpu_search_locate_packed(const bwtgpu_index *ix, const uint32_t *d_words,
  * or by the first call on that device).  The call itself allocates nothing,
  * which includes the search-only arrays of bwtgpu_index_prepare_search: it
  * uses them when they are there and searches on the rank blocks when not.
+ * It may run while another thread's first bwtgpu_search on the same index is
+ * still making those arrays: it takes them only once all of them are complete
+ * (the same holds for bwtgpu_locate_rows and the suffix array of a loaded
+ * index); bwtgpu_index_compact and bwtgpu_index_free are the callers' to keep
+ * apart from searches in flight.
  * Reads short enough to be packed inside the search kernel (up to about 1700
  * bases at stride = m) use no scratch and any R is accepted; for longer reads
  * ((m+15)/16) * 4 * R + 512 bytes must fit the 16 MiB, else the call fails with
