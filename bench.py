@@ -45,6 +45,39 @@ def rank_only_bytes_per_read(m, locate_steps=None):
     return b
 
 
+def roofline_extras(m, R, k_ms, missed_lines, gather_lines, locate_steps=None):
+    """The two other ways to price the search kernel, beside bytes requested / HBM peak.
+
+    survey: the byte count of a search made of rank queries alone (one 32-byte block per query,
+    2 (m - 1) queries a read, seqindex.c:280-309 + :91-111; with locate, one block per LF step of
+    unc_sa, :244-255) divided by this kernel's time.  The kernel answers loc_search / locate
+    without most of those queries (one table lookup for the read's last K bases, one comparison
+    with the text for the rest), so this comes out above the HBM peak: it says how many times
+    the rank-query formulation's traffic the kernel avoids, not how fast memory is.
+    line_rate: what does bound it -- 64-byte lines fetched past the L2 per second (PMC, from the
+    committed passes) against plain random 4-byte gathers over 8 GiB measured in this run."""
+    bpr = rank_only_bytes_per_read(m, locate_steps)
+    ach = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+    out = {"survey": {"bytes_per_read": bpr, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": ach / HBM_PEAK_GBS,
+                      "what": "m/4 + 32 B x 2(m-1) rank queries" +
+                              (f" + 32 B x {locate_steps} LF steps + 4" if locate_steps is not None else "") +
+                              " + 8, over this kernel's time; above 1 because the kernel answers without "
+                              "most of those queries (k-mer table start + text comparison), results "
+                              "bit-identical to the rank-only search of the same batch"}}
+    if missed_lines and k_ms:
+        lps = missed_lines / (k_ms * 1e-3)
+        out["line_rate"] = {"l2_missed_lines_per_launch": missed_lines, "l2_missed_lines_per_s": lps,
+                            "lines_per_read": missed_lines / R,
+                            "random_gather_lines_per_s": gather_lines,
+                            "frac": lps / gather_lines if gather_lines else None,
+                            "what": "64-byte lines that miss the L2 per second (TCC_MISS_sum of the committed PMC "
+                                    "pass / kernel time of this run) over the rate of plain random 4-byte "
+                                    "gathers measured in this run: the bound of a kernel whose loads have no "
+                                    "locality; above 1 where records and rank blocks are found in the last-level cache"}
+    return out
+
+
 def time_callers(ix, d_text, n, R=1_000_000, m=100):
     """Kernel rates of the functions that call the search path (seqindex.c:314-351 mms,
     search_reads.c:115-153, single_align.c:163-298) on one batch of edited reads."""
@@ -180,13 +213,13 @@ def c5_leg(args):
     return out
 
 
-def bench_c4(args, rank, world, dist, barrier, red_dev):
+def run_c4(args, rank, world, dist, barrier, red_dev, n, R_all, m, steps, warmup):
     """BASELINE.json configs[3]: 3.1 Gbp, index replicated, ONE set of reads partitioned over the
     ranks (the static split of fmitest.c:67-91), each read searched and located.  Strong scaling:
-    value = reads of the whole set / time of the slowest rank."""
+    value = reads of the whole set / time of the slowest rank.  Returns the result on rank 0,
+    None on the others."""
     from bwt_amd import dist as D
 
-    n, R_all, m = args.genome_bp, args.reads, args.read_len
     d_text = G.gen_genome(n, synth.GENOME_SEED)
     torch.cuda.synchronize()
     G.timing_enable(False)
@@ -215,13 +248,13 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
     def step():  # loc_search and locate() of every read: one call, one kernel on an index with position records
         ix.search_locate(d_reads, m, R, out=(sp, ep, pos))
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     G.timing_enable(True)
     G.timing_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -273,8 +306,7 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
                 same_output = same_output and bool(torch.equal(want.cpu(), all_sums[g].cpu()))
                 del rg, a, b, c, p, w
     if rank != 0:
-        dist.destroy_process_group()
-        return
+        return None
 
     ns, ms_s = kernels.get("fm_search", (0, 0.0))
     nl, ms_l = two_calls.get("fm_locate", (0, 0.0))
@@ -285,15 +317,21 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
     bpr = (loads["bytes"] - 4 * loads["pattern_words_4B"]) / R + m + 12.0
     achieved = bpr * R / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
     traffic = measured_traffic(f"{n}bp_{R_all}x{m}") if world == 1 else None
+    missed = measured_traffic(f"{n}bp_{R_all}x{m}_l2_misses") if world == 1 else None
+    try:
+        gather_lines = G.gather_rate(8) if world == 1 else None
+    except Exception:  # noqa: BLE001 - a probe, not a result
+        gather_lines = None
+    extras = roofline_extras(m, R, k_ms, missed, gather_lines, locate_steps=15.5)
     build_s, prep_s = build_ms[-1] / 1e3, prep_ms[-1] / 1e3
     result = {
         "metric": "SA build Mbp/s; FM backward-search reads/s (1/2/4/8 GPU); % HBM peak",
-        "value": R_all * args.steps / elapsed,
+        "value": R_all * steps / elapsed,
         "unit": "reads/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -319,6 +357,7 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
             "what": "rank 0's slice; the step is ONE kernel (bwtgpu_search_locate: intervals and positions); bytes "
                     "counted by the kernel's counting build, which leaves out the suffix-array entry a repeated "
                     "read's position costs",
+            **extras,
         },
         "search_then_locate": {"search_kernel_ms": ms_s2 / max(ns2, 1), "locate_kernel_ms": l_ms,
                                "locate_value": R / (l_ms * 1e-3) if l_ms else None, "unit": "rows/s",
@@ -341,7 +380,17 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
                              "reference timed on this box",
         "index_bytes": ix.device_bytes,
     }
-    print(json.dumps(result), flush=True)
+    ix.close()
+    del d_reads, d_offs, sp, ep, lr, pos, d_text
+    G._lib.load().bwtgpu_release_cache()
+    return result
+
+
+def bench_c4(args, rank, world, dist, barrier, red_dev):
+    result = run_c4(args, rank, world, dist, barrier, red_dev, args.genome_bp, args.reads, args.read_len,
+                    args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -357,6 +406,9 @@ def main():
     ap.add_argument("--reads", type=int, default=None, help="c2: reads per GPU per step; c4: reads in the one set")
     ap.add_argument("--read-len", type=int, default=None)
     ap.add_argument("--no-c5", action="store_true", help="skip the tandem-repeat build leg (c2, one GPU)")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the 3.1 Gbp / 100 M x 100 bp leg of the default line (c2, one GPU)")
+    ap.add_argument("--c4-steps", type=int, default=5, help="timed steps of that leg")
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")
@@ -757,6 +809,7 @@ def main():
                     "(16 B rank blocks, 16 B text windows, 4 B SA/ISA entries and further table starts, 8 B table entry, "
                     "the read itself, 12 B out)",
             "reads_packed_in_kernel": fused,
+            **roofline_extras(m, R, k_ms, measured_traffic(f"{n}bp_{R}x{m}_l2_misses"), gather_lines),
         },
         "packed_input": packed_leg,
         "loaded_index": loaded_leg,
@@ -822,6 +875,21 @@ def main():
         gs = G.to_numpy_u32(sp[: args.cpu_reads])
         ge = G.to_numpy_u32(ep[: args.cpu_reads])
         result["cpu_baseline"] = cpu_baseline(args, d_text, n, d_reads, R, m, gs, ge)
+    if world == 1 and not args.no_c4:
+        # ---- BASELINE.json configs[3] on this one GPU, after everything of the 46 Mbp legs has been released ----
+        try:
+            ix.close()
+            del ix, d_text, d_reads, sp, ep, lr, sp2, ep2, lr2, pos, pos2
+            G._lib.load().bwtgpu_release_cache()
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            c4 = run_c4(args, 0, 1, None, barrier, red_dev, 3_100_000_000, 100_000_000, 100, args.c4_steps, 2)
+            c4["leg_wall_s"] = time.perf_counter() - t0
+            for k in ("metric", "higher_is_better", "vs_baseline", "data", "n_gpus"):
+                c4.pop(k, None)
+            result["c4"] = c4
+        except Exception as e:  # noqa: BLE001 - the headline does not depend on this
+            result["c4"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if dist is not None:
         # the sharded build comes last, on a timer: if one of its collectives never
         # returns, the line goes out without it
