@@ -130,7 +130,16 @@ std::mutex g_pin_mu;
 std::vector<Pinned> g_pin_idle;
 }  // namespace
 
+// Staging sizes follow the batch (chunk = min(R, ...)): rounded up to a power of two so
+// that callers whose batches vary in size find the buffers of the call before.
+static size_t pinned_round(size_t bytes) {
+  size_t r = 64u << 10;
+  while (r < bytes) r <<= 1;
+  return r;
+}
+
 static void *pinned_get(size_t bytes) {
+  bytes = pinned_round(bytes);
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     for (size_t i = 0; i < g_pin_idle.size(); ++i)
@@ -141,7 +150,8 @@ static void *pinned_get(size_t bytes) {
       }
   }
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+  // portable: the staging of one call may be reused by a call on another GPU
+  if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
   }
@@ -150,6 +160,7 @@ static void *pinned_get(size_t bytes) {
 
 static void pinned_put(void *p, size_t bytes) {
   if (!p) return;
+  bytes = pinned_round(bytes);
   void *drop = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_pin_mu);
@@ -171,6 +182,47 @@ void pinned_release_idle() {
   for (const Pinned &d : drop) (void)hipHostFree(d.p);
 }
 
+// ---- streams and events of the pipeline's slots, kept between calls --------------------
+
+namespace {
+struct Lane {
+  hipStream_t stream;
+  hipEvent_t done;
+  int device;
+};
+std::mutex g_lane_mu;
+std::vector<Lane> g_lane_idle;
+}  // namespace
+
+static hipError_t lane_get(hipStream_t *stream, hipEvent_t *done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    for (size_t i = 0; i < g_lane_idle.size(); ++i)
+      if (g_lane_idle[i].device == dev) {
+        *stream = g_lane_idle[i].stream;
+        *done = g_lane_idle[i].done;
+        g_lane_idle.erase(g_lane_idle.begin() + (long)i);
+        return hipSuccess;
+      }
+  }
+  e = hipStreamCreateWithFlags(stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(done, hipEventDisableTiming);
+  return e;
+}
+
+static void lane_put(hipStream_t stream, hipEvent_t done, int device) {
+  if (!stream || !done) {
+    if (done) (void)hipEventDestroy(done);
+    if (stream) (void)hipStreamDestroy(stream);
+    return;
+  }
+  std::lock_guard<std::mutex> lk(g_lane_mu);
+  g_lane_idle.push_back(Lane{stream, done, device});
+}
+
 // ---- the pipeline ------------------------------------------------------------------------------
 
 constexpr int kSlots = 3;                       // chunks in flight
@@ -189,6 +241,7 @@ struct Slot {
 struct PipeBuffers {
   Slot slot[kSlots];
   size_t in_bytes = 0, out_bytes = 0;
+  int device = 0;
   ~PipeBuffers() {
     for (Slot &s : slot) {
       if (s.stream) (void)hipStreamSynchronize(s.stream);
@@ -197,13 +250,15 @@ struct PipeBuffers {
       pool_free(s.d_in);
       pool_free(s.d_out);
       pool_free(s.d_lws);
-      if (s.done) (void)hipEventDestroy(s.done);
-      if (s.stream) (void)hipStreamDestroy(s.stream);
+      lane_put(s.stream, s.done, device);
     }
   }
   int open(uint64_t chunk, uint32_t words) {
-    in_bytes = chunk * words * 4;
-    out_bytes = chunk * 16;
+    // device buffers come from the exact-size pool: rounded like the pinned ones, so that
+    // batches of varying size find them again
+    in_bytes = pinned_round(chunk * words * 4);
+    out_bytes = pinned_round(chunk * 16);
+    (void)hipGetDevice(&device);
     for (Slot &s : slot) {
       s.h_in = static_cast<uint32_t *>(pinned_get(in_bytes));
       s.h_out = static_cast<uint32_t *>(pinned_get(out_bytes));
@@ -211,8 +266,7 @@ struct PipeBuffers {
       hipError_t e = pool_alloc(&s.d_in, in_bytes);
       if (e == hipSuccess) e = pool_alloc(&s.d_out, out_bytes);
       if (e == hipSuccess) e = pool_alloc(&s.d_lws, bwtgpu_locate_workspace_bytes());
-      if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+      if (e == hipSuccess) e = lane_get(&s.stream, &s.done);
       if (e != hipSuccess) return set_error(kErrHip, "staging buffers: %s", hipGetErrorString(e));
     }
     return kOk;

@@ -828,6 +828,76 @@ int bwtgpu_index_prepare_search(bwtgpu_index *ix, void *stream) {
   return index_ready_for_search(ix, (hipStream_t)stream);
 }
 
+bwtgpu_index *bwtgpu_index_replicate(const bwtgpu_index *src, int device) {
+  if (!src) {
+    set_error(kErrArg, "null index");
+    return nullptr;
+  }
+  int ndev = 0, cur = -1;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_error(kErrArg, "device %d out of range (have %d)", device, ndev);
+    return nullptr;
+  }
+  if (hipGetDevice(&cur) != hipSuccess || hipSetDevice(device) != hipSuccess) {
+    set_error(kErrHip, "cannot make device %d current", device);
+    return nullptr;
+  }
+  bwtgpu_index *ix = nullptr;
+  int rc = index_alloc(&ix, src->n);
+  if (rc == kOk) {
+    if (device != src->device) {  // direct access where the link allows it; the copies below work either way
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can)
+        (void)hipDeviceEnablePeerAccess(src->device, 0);
+      (void)hipGetLastError();  // "already enabled" is not an error
+    }
+    auto copy = [&](void *dst, const void *from, size_t bytes) {
+      return device == src->device ? hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, nullptr)
+                                   : hipMemcpyPeerAsync(dst, device, from, src->device, bytes, nullptr);
+    };
+    const uint32_t n = src->n;
+    const size_t rows = (size_t)n + 1, t2words = (size_t)n / 16 + 4;
+    // the source's suffix array and text words stay as they are while we hold its lock
+    std::lock_guard<std::mutex> lock(src->prepare_mu);
+    hipError_t e = copy(ix->d_blocks, src->d_blocks, ix->nblocks * sizeof(IndexBlock));
+    if (e == hipSuccess) e = copy(ix->d_sym, src->d_sym, 4 * ix->nsym * sizeof(SymBlock));
+    if (e == hipSuccess) e = copy(ix->d_idxs, src->d_idxs, (((size_t)n >> kDevSampleShift) + 1) * sizeof(uint32_t));
+    uint32_t *sa = nullptr, *text2 = nullptr;
+    if (e == hipSuccess && src->d_sa && src->d_text2 && !getenv("BWT_MI355X_COMPACT")) {
+      if (pool_alloc(&sa, rows * 4) == hipSuccess && pool_alloc(&text2, t2words * 4) == hipSuccess) {
+        e = copy(sa, src->d_sa, rows * 4);
+        if (e == hipSuccess) e = copy(text2, src->d_text2, t2words * 4);
+      } else {  // no room: the copy searches on its rank blocks
+        (void)hipGetLastError();
+        pool_free(sa);
+        pool_free(text2);
+        sa = text2 = nullptr;
+      }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+      (void)hipDeviceSynchronize();
+      pool_free(sa);
+      pool_free(text2);
+      rc = set_error(kErrHip, "copying the index to device %d: %s", device, hipGetErrorString(e));
+    } else {
+      ix->endloc = src->endloc;
+      for (int c = 0; c < 5; ++c) ix->C[c] = src->C[c];
+      ix->has_samples = src->has_samples;
+      ix->d_sa = sa;
+      ix->d_text2 = text2;
+      ix->want_recover = !sa && src->want_recover;
+      index_defer_search_arrays(ix);
+    }
+  }
+  (void)hipSetDevice(cur);
+  if (rc != kOk) {
+    if (ix) bwtgpu_index_free(ix);
+    return nullptr;
+  }
+  return ix;
+}
+
 int bwtgpu_index_export(const bwtgpu_index *ix, uint8_t *h_bwt, uint32_t *h_idxs) {
   if (!ix) return set_error(kErrArg, "null index");
   BWT_HIP(hipSetDevice(ix->device));

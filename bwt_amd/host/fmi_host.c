@@ -32,13 +32,58 @@
 /* device selection and the fm_index -> device index registry          */
 /* ------------------------------------------------------------------ */
 
-static int device_ready(void) {
-  /* every host thread that enters the API makes the device current */
-  const char *env = getenv("BWT_MI355X_DEVICE");
-  int dev = env ? atoi(env) : 0;
-  int rc = bwtgpu_init(dev);
+/* The GPUs this layer uses.  BWT_MI355X_DEVICES = "all" or a comma-separated list
+ * of ordinals (an ordinal may be listed more than once: each mention is a slot
+ * with a replica of its own, which is how the partitioning is tested on a
+ * one-GPU machine); else BWT_MI355X_DEVICE = one ordinal; else every visible GPU.
+ * Slot 0 is the primary: builds, loads, single queries and small batches run
+ * there.  The other slots get a replica of an index the first time a batch is
+ * large enough to be split (fmi_*_batch below), and from then on take their
+ * contiguous share of every such batch: the static split over worker threads of
+ * fmitest.c:67-91, with a GPU behind each worker.  A process that is itself one
+ * of several (one per GPU) sets BWT_MI355X_DEVICE to its own GPU. */
+#define FMI_MAX_SLOTS 16
+static int g_slot_dev[FMI_MAX_SLOTS];
+static int g_nslots;
+static long g_min_reads_per_slot = 65536;
+static pthread_once_t g_slots_once = PTHREAD_ONCE_INIT;
+
+static void slots_init(void) {
+  const char *list = getenv("BWT_MI355X_DEVICES");
+  const char *one = getenv("BWT_MI355X_DEVICE");
+  const char *mr = getenv("BWT_MI355X_MIN_READS_PER_DEVICE");
+  if (mr && atol(mr) > 0) g_min_reads_per_slot = atol(mr);
+  if (list && strcmp(list, "all") != 0) {
+    const char *p = list;
+    while (*p && g_nslots < FMI_MAX_SLOTS) {
+      char *end;
+      long d = strtol(p, &end, 10);
+      if (end == p) break;
+      g_slot_dev[g_nslots++] = (int)d;
+      p = *end == ',' ? end + 1 : end;
+    }
+  } else if (!list && one) {
+    g_slot_dev[g_nslots++] = atoi(one);
+  } else {
+    int n = bwtgpu_device_count();
+    for (int d = 0; d < n && g_nslots < FMI_MAX_SLOTS; ++d) g_slot_dev[g_nslots++] = d;
+  }
+  if (g_nslots == 0) g_slot_dev[g_nslots++] = 0; /* bwtgpu_init then says what is wrong */
+}
+
+static int slot_ready(int slot) {
+  /* every host thread that enters the API makes its device current */
+  pthread_once(&g_slots_once, slots_init);
+  int rc = bwtgpu_init(g_slot_dev[slot]);
   if (rc) fprintf(stderr, "bwt_mi355x: %s\n", bwtgpu_last_error());
   return rc;
+}
+
+static int device_ready(void) { return slot_ready(0); }
+
+int fmi_device_slots(void) {
+  pthread_once(&g_slots_once, slots_init);
+  return g_nslots;
 }
 
 static void report(const char *what) {
@@ -47,7 +92,9 @@ static void report(const char *what) {
 
 struct reg_entry {
   const fm_index *fmi;
-  bwtgpu_index *ix;
+  bwtgpu_index *ix;                      /* on slot 0 */
+  bwtgpu_index *replica[FMI_MAX_SLOTS];  /* [0] unused; made on first use of the slot */
+  pthread_mutex_t replica_lock[FMI_MAX_SLOTS];
   int *rank_slab; /* rows of rank_index, one allocation */
   struct reg_entry *next;
 };
@@ -55,10 +102,11 @@ static struct reg_entry *g_reg;
 static pthread_mutex_t g_reg_lock = PTHREAD_MUTEX_INITIALIZER;
 
 static void reg_put(const fm_index *fmi, bwtgpu_index *ix, int *rank_slab) {
-  struct reg_entry *e = malloc(sizeof *e);
+  struct reg_entry *e = calloc(1, sizeof *e);
   e->fmi = fmi;
   e->ix = ix;
   e->rank_slab = rank_slab;
+  for (int g = 0; g < FMI_MAX_SLOTS; ++g) pthread_mutex_init(&e->replica_lock[g], NULL);
   pthread_mutex_lock(&g_reg_lock);
   e->next = g_reg;
   g_reg = e;
@@ -74,22 +122,95 @@ static struct reg_entry *reg_find_locked(const fm_index *fmi) {
 /* The device index behind an fm_index.  One that did not come from make_fmi
  * or read_index (a caller filled the struct itself) is uploaded on first use
  * from its stored parts, as read_index would. */
-static bwtgpu_index *device_index(const fm_index *fmi) {
+static struct reg_entry *device_entry(const fm_index *fmi) {
   if (!fmi) return NULL;
   pthread_mutex_lock(&g_reg_lock);
   struct reg_entry *e = reg_find_locked(fmi);
-  bwtgpu_index *ix = e ? e->ix : NULL;
   pthread_mutex_unlock(&g_reg_lock);
-  if (ix) return device_ready() ? NULL : ix;
   if (device_ready()) return NULL;
-  ix = bwtgpu_index_from_parts((const uint8_t *)fmi->bwt, (uint32_t)fmi->len, (uint32_t)fmi->endloc,
-                               (const uint32_t *)fmi->idxs, NULL);
+  if (e) return e;
+  bwtgpu_index *ix = bwtgpu_index_from_parts((const uint8_t *)fmi->bwt, (uint32_t)fmi->len, (uint32_t)fmi->endloc,
+                                             (const uint32_t *)fmi->idxs, NULL);
   if (!ix) {
     report("index upload");
     return NULL;
   }
   reg_put(fmi, ix, NULL);
+  pthread_mutex_lock(&g_reg_lock);
+  e = reg_find_locked(fmi);
+  pthread_mutex_unlock(&g_reg_lock);
+  return e;
+}
+
+static bwtgpu_index *device_index(const fm_index *fmi) {
+  struct reg_entry *e = device_entry(fmi);
+  return e ? e->ix : NULL;
+}
+
+/* the index of slot g > 0: a copy of the primary in that GPU's memory, made once */
+static bwtgpu_index *replica_index(struct reg_entry *e, int g) {
+  pthread_mutex_lock(&e->replica_lock[g]);
+  if (!e->replica[g]) {
+    e->replica[g] = bwtgpu_index_replicate(e->ix, g_slot_dev[g]);
+    if (!e->replica[g]) report("index replica");
+  }
+  bwtgpu_index *ix = e->replica[g];
+  pthread_mutex_unlock(&e->replica_lock[g]);
   return ix;
+}
+
+/* A batch of `count` independent items over the slots: slot g takes the contiguous
+ * share fmi_share_bounds gives it, each share on a host thread of its own with
+ * its GPU current, the caller's thread taking share 0.  `fn` runs one share on one
+ * index and returns 0 or -1; results land in the caller's arrays at the share's
+ * offset, so they come out in item order.  Batches too small to give every slot
+ * min_reads_per_slot items use fewer slots, down to the primary alone. */
+typedef int (*share_fn)(bwtgpu_index *ix, long lo, long hi, void *ctx);
+struct share_job {
+  struct reg_entry *e;
+  int slot;
+  long lo, hi;
+  share_fn fn;
+  void *ctx;
+  int rc;
+  pthread_t th;
+};
+
+void fmi_share_bounds(long count, int shares, int g, long *lo, long *hi) {
+  const long base = count / shares, extra = count % shares; /* the first `extra` shares hold one item more */
+  *lo = g * base + (g < extra ? g : extra);
+  *hi = *lo + base + (g < extra ? 1 : 0);
+}
+
+static void *share_worker(void *arg) {
+  struct share_job *j = arg;
+  j->rc = -1;
+  if (slot_ready(j->slot)) return NULL;
+  bwtgpu_index *ix = replica_index(j->e, j->slot);
+  if (ix) j->rc = j->fn(ix, j->lo, j->hi, j->ctx);
+  return NULL;
+}
+
+static int run_shared(const fm_index *fmi, long count, share_fn fn, void *ctx) {
+  struct reg_entry *e = device_entry(fmi);
+  if (!e) return -1;
+  int G = g_nslots;
+  if (count < g_min_reads_per_slot * (long)G) G = (int)(count / g_min_reads_per_slot);
+  if (G <= 1) return fn(e->ix, 0, count, ctx);
+  struct share_job job[FMI_MAX_SLOTS];
+  for (int g = 0; g < G; ++g) {
+    job[g] = (struct share_job){.e = e, .slot = g, .fn = fn, .ctx = ctx, .rc = -1};
+    fmi_share_bounds(count, G, g, &job[g].lo, &job[g].hi);
+  }
+  int started[FMI_MAX_SLOTS] = {0};
+  for (int g = 1; g < G; ++g) started[g] = pthread_create(&job[g].th, NULL, share_worker, &job[g]) == 0;
+  int rc = fn(e->ix, job[0].lo, job[0].hi, ctx);
+  for (int g = 1; g < G; ++g) {
+    if (started[g]) pthread_join(job[g].th, NULL);
+    else share_worker(&job[g]), device_ready(); /* no thread to be had: the share runs here, then back to the primary */
+    if (job[g].rc) rc = -1;
+  }
+  return rc;
 }
 
 /* ------------------------------------------------------------------ */
@@ -265,6 +386,10 @@ void destroy_fmi(fm_index *fmi) {
   pthread_mutex_unlock(&g_reg_lock);
   if (e) {
     bwtgpu_index_free(e->ix);
+    for (int g = 1; g < FMI_MAX_SLOTS; ++g) {
+      if (e->replica[g]) bwtgpu_index_free(e->replica[g]);
+      pthread_mutex_destroy(&e->replica_lock[g]);
+    }
     if (e->rank_slab) {
       free(e->rank_slab);
       free(fmi->rank_index);
@@ -613,54 +738,72 @@ int locate(const fm_index *fmi, const char *pattern, int len) {
 /* batch forms                                                         */
 /* ------------------------------------------------------------------ */
 
-int fmi_search_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
-                     int *sp, int *ep) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
-  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
-                         (uint32_t *)sp, (uint32_t *)ep, NULL, NULL)) {
+struct search_ctx {
+  const char *pats;
+  const unsigned *words;
+  int len;
+  long stride;
+  int *sp, *ep, *pos, *result;
+};
+#define AT(p, lo) ((p) ? (p) + (lo) : NULL)
+
+static int share_search(bwtgpu_index *ix, long lo, long hi, void *vc) {
+  const struct search_ctx *c = vc;
+  if (bwtgpu_search_host(ix, (const uint8_t *)c->pats + lo * c->stride, (uint32_t)c->len, (uint64_t)c->stride,
+                         (uint64_t)(hi - lo), (uint32_t *)AT(c->sp, lo), (uint32_t *)AT(c->ep, lo), NULL,
+                         (uint32_t *)AT(c->pos, lo))) {
     report("search");
     return -1;
   }
   return 0;
 }
 
-int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
-                             long nreads, int *result) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
+static int share_reverse_search(bwtgpu_index *ix, long lo, long hi, void *vc) {
+  const struct search_ctx *c = vc;
   /* seqindex.c:233-241, evaluated on the device: one int per read comes back */
-  if (bwtgpu_reverse_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
-                                 (int32_t *)result)) {
+  if (bwtgpu_reverse_search_host(ix, (const uint8_t *)c->pats + lo * c->stride, (uint32_t)c->len,
+                                 (uint64_t)c->stride, (uint64_t)(hi - lo), (int32_t *)c->result + lo)) {
     report("reverse_search");
     return -1;
   }
   return 0;
 }
 
-int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
-                     int *pos) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
-  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
-                         NULL, NULL, NULL, (uint32_t *)pos)) {
-    report("locate");
+static int share_search_packed(bwtgpu_index *ix, long lo, long hi, void *vc) {
+  const struct search_ctx *c = vc;
+  const long words = (c->len + 15) / 16;
+  if (bwtgpu_search_packed_host(ix, c->words + lo * words, (uint32_t)c->len, (uint64_t)(hi - lo),
+                                (uint32_t *)AT(c->sp, lo), (uint32_t *)AT(c->ep, lo), NULL,
+                                (uint32_t *)AT(c->pos, lo))) {
+    report("packed search");
     return -1;
   }
-  return 0; /* 0xFFFFFFFF reads as -1 */
+  return 0;
+}
+
+int fmi_search_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                     int *sp, int *ep) {
+  struct search_ctx c = {.pats = pats, .len = len, .stride = stride, .sp = sp, .ep = ep};
+  return run_shared(fmi, nreads, share_search, &c);
+}
+
+int fmi_reverse_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
+                             long nreads, int *result) {
+  struct search_ctx c = {.pats = pats, .len = len, .stride = stride, .result = result};
+  return run_shared(fmi, nreads, share_reverse_search, &c);
+}
+
+int fmi_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
+                     int *pos) {
+  struct search_ctx c = {.pats = pats, .len = len, .stride = stride, .pos = pos};
+  return run_shared(fmi, nreads, share_search, &c); /* 0xFFFFFFFF reads as -1 */
 }
 
 int fmi_search_locate_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
                             int *sp, int *ep, int *pos) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
   /* one pass over the reads: an index with position records has the positions by the time it has the intervals */
-  if (bwtgpu_search_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
-                         (uint32_t *)sp, (uint32_t *)ep, NULL, (uint32_t *)pos)) {
-    report("search and locate");
-    return -1;
-  }
-  return 0;
+  struct search_ctx c = {.pats = pats, .len = len, .stride = stride, .sp = sp, .ep = ep, .pos = pos};
+  return run_shared(fmi, nreads, share_search, &c);
 }
 
 void fmi_pack_reads(const char *pats, int len, long stride, long nreads, unsigned *words) {
@@ -671,21 +814,41 @@ void fmi_pack_reads(const char *pats, int len, long stride, long nreads, unsigne
 
 int fmi_search_batch_packed(const fm_index *fmi, const unsigned *words, int len, long nreads,
                             int *sp, int *ep, int *pos) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
-  if (bwtgpu_search_packed_host(ix, words, (uint32_t)len, (uint64_t)nreads, (uint32_t *)sp, (uint32_t *)ep, NULL,
-                                (uint32_t *)pos)) {
-    report("packed search");
+  struct search_ctx c = {.words = words, .len = len, .sp = sp, .ep = ep, .pos = pos};
+  return run_shared(fmi, nreads, share_search_packed, &c);
+}
+
+struct rows_ctx {
+  const int *rows;
+  int *pos;
+};
+
+static int share_unc_sa(bwtgpu_index *ix, long lo, long hi, void *vc) {
+  const struct rows_ctx *c = vc;
+  if (bwtgpu_locate_rows_host(ix, (const uint32_t *)c->rows + lo, (uint64_t)(hi - lo), (uint32_t *)c->pos + lo)) {
+    report("unc_sa");
     return -1;
   }
   return 0;
 }
 
 int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
-  if (bwtgpu_locate_rows_host(ix, (const uint32_t *)rows, (uint64_t)nrows, (uint32_t *)pos)) {
-    report("unc_sa");
+  struct rows_ctx c = {rows, pos};
+  return run_shared(fmi, nrows, share_unc_sa, &c);
+}
+
+struct mms_ctx {
+  const char *pats;
+  int len;
+  long stride;
+  int *matched, *sp, *ep;
+};
+
+static int share_mms(bwtgpu_index *ix, long lo, long hi, void *vc) {
+  const struct mms_ctx *c = vc;
+  if (bwtgpu_mms_host(ix, (const uint8_t *)c->pats + lo * c->stride, (uint32_t)c->len, (uint64_t)c->stride,
+                      (uint64_t)(hi - lo), c->matched + lo, (uint32_t *)c->sp + lo, (uint32_t *)c->ep + lo)) {
+    report("mms");
     return -1;
   }
   return 0;
@@ -693,14 +856,8 @@ int fmi_unc_sa_batch(const fm_index *fmi, const int *rows, long nrows, int *pos)
 
 int fmi_mms_batch(const fm_index *fmi, const char *pats, int len, long stride, long nreads,
                   int *matched, int *sp, int *ep) {
-  bwtgpu_index *ix = device_index(fmi);
-  if (!ix) return -1;
-  if (bwtgpu_mms_host(ix, (const uint8_t *)pats, (uint32_t)len, (uint64_t)stride, (uint64_t)nreads,
-                      matched, (uint32_t *)sp, (uint32_t *)ep)) {
-    report("mms");
-    return -1;
-  }
-  return 0;
+  struct mms_ctx c = {pats, len, stride, matched, sp, ep};
+  return run_shared(fmi, nreads, share_mms, &c);
 }
 
 int mms(const fm_index *fmi, const char *pattern, int len, int *sp, int *ep) {

@@ -199,6 +199,18 @@ int bwtgpu_index_compact(bwtgpu_index *ix);
  * is short they are left out, which is not an error.  No counterpart in the
  * reference. */
 int bwtgpu_index_prepare_search(bwtgpu_index *ix, void *stream);
+/* A second copy of an index in the memory of GPU `device` (which may be the one
+ * it already lives on): what make_fmi produces -- rank blocks, BWT planes,
+ * sampled rows -- and, when the source keeps them, the suffix array and the
+ * text words travel by peer-to-peer copies (1.67 + 4.25 bytes per base); the
+ * copy makes its own search-only arrays on its first search, which on these
+ * GPUs is quicker than moving them (3.1 Gbp: 68 ms against 56 GB over a link).
+ * A loaded source that has not recomputed its suffix array yet hands the copy
+ * the same task.  The replicated-index form of a multi-GPU search: the
+ * reference's analogue is the one fm_index its four worker threads share
+ * (fmitest.c:67-91).  Leaves the calling thread's current device as it was.
+ * NULL on failure. */
+bwtgpu_index *bwtgpu_index_replicate(const bwtgpu_index *src, int device);
 
 /* ---- certificates (no counterpart in the reference: its lengths are int, so
  * beyond 2^31 - 1 bases there is no reference output to compare with) ---- */

@@ -89,7 +89,24 @@ fm_index *read_index(const char *seq, FILE *f);
 
 /* ---- batch forms (no counterpart in the reference) ---- */
 /* Read r is the len bytes at pats + r*stride, bases 0..3 one per byte.
- * All return 0, or -1 after printing the device error to stderr. */
+ * All return 0, or -1 after printing the device error to stderr.
+ *
+ * Several GPUs: the index is replicated and the reads are partitioned, the
+ * static split over worker threads of fmitest.c:67-91 with a GPU behind each
+ * worker.  The GPUs are those of BWT_MI355X_DEVICES ("all", or a comma-separated
+ * list of ordinals; an ordinal listed twice is two slots on one GPU), else the
+ * one of BWT_MI355X_DEVICE, else every visible GPU.  make_fmi / read_index build
+ * or load on the first; the first batch of at least
+ * BWT_MI355X_MIN_READS_PER_DEVICE (65536) reads per GPU copies the index to the
+ * others (peer-to-peer), and from then on fmi_search_batch, _reverse_search_,
+ * _locate_, _search_locate_, _search_batch_packed, _unc_sa_ and _mms_batch hand
+ * GPU g a contiguous share of their n reads (fmi_share_bounds) on a host
+ * thread of its own and return when all shares are done, results in read order.
+ * fmi_search_reads_batch and fmi_align_reads_batch run on the first GPU.  A
+ * process that is one of several, one per GPU, sets BWT_MI355X_DEVICE. */
+int fmi_device_slots(void); /* how many GPUs (slots) the batch forms spread over */
+/* the share of slot g of `shares`: items [*lo, *hi) of `count` */
+void fmi_share_bounds(long count, int shares, int g, long *lo, long *hi);
 /* loc_search per read: sp[r], ep[r] */
 int fmi_search_batch(const fm_index *fmi, const char *pats, int len, long stride,
                      long nreads, int *sp, int *ep);
