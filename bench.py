@@ -200,15 +200,88 @@ def c5_leg(args):
            "roofline": {"bound": "hbm", "bytes_per_bp": 4.25, "achieved": 4.25 * n / dt / 1e9, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": 4.25 * n / dt / 1e9 / HBM_PEAK_GBS}}
     ref = None if (args.no_cpu or args.cpu_port) else load_reference()
+    sa_same = None
     if ref is not None:
         t0 = time.perf_counter()
         sa_ref = ref.csuff_arr(text, n)
         dc = time.perf_counter() - t0
+        sa_same = bool((np.asarray(sa_ref, np.uint32) == G.to_numpy_u32(sa)).all())
         out["cpu_baseline"] = {"value": n / dc / 1e6, "unit": "Mbp/s", "cores": 1, "kind": "reference",
                                "sample": "the whole 100 Mbp text through csuff_arr (SACA-K is sequential)",
-                               "seconds": dc,
-                               "gpu_matches_cpu": bool((np.asarray(sa_ref, np.uint32) == G.to_numpy_u32(sa)).all())}
-    del sa, d_text
+                               "seconds": dc, "gpu_matches_cpu": sa_same}
+        del sa_ref
+    # ---- backward search on this text: wide intervals, where the k-mer table and the text comparison
+    # help least (seqindex.c:298-306 goes on with rank steps while an interval holds several rows) ----
+    try:
+        R, m = 10_000_000, 50
+        sa_h = G.to_numpy_u32(sa) if not args.no_cpu else None
+        del sa
+        ix = G.build_index_dev(d_text, n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ix.prepare_search()
+        torch.cuda.synchronize()
+        prep_ms = (time.perf_counter() - t0) * 1e3
+        d_reads, d_offs = G.gen_reads(d_text, n, R, m, synth.READS_SEED + 50)
+        sp, ep, pos = (torch.empty(R, dtype=torch.int32, device="cuda") for _ in range(3))
+        for _ in range(2):
+            ix.search_locate(d_reads, m, R, out=(sp, ep, pos))
+        G.timing_enable(True)
+        G.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.c5_steps):
+            ix.search_locate(d_reads, m, R, out=(sp, ep, pos))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.c5_steps
+        k_n, k_ms = G.timing_report().get("fm_search", (0, 0.0))
+        G.timing_enable(False)
+        loads, sp_c, ep_c = ix.search_loads(d_reads, m, R)
+        cut = d_offs != -1
+        width = (ep - sp).to(torch.int64)
+        # locate() of a read gives the text position of the first row of its interval: the read must stand there
+        lines = (loads["rank_blocks_16B"] + loads["text_windows_16B"] + loads["sa_isa_entries_4B"] / 2
+                 + loads["kmer_entries"]) / R
+        leg = {"workload": f"{R} x {m} bp reads cut from this text (1% random), search + locate of the first row, one kernel",
+               "value": R / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "kernel_ms": k_ms / max(k_n, 1),
+               "search_arrays_ms": prep_ms,
+               "rows_per_interval_mean": float(width[cut].double().mean()),
+               "reads_with_one_row": float((width[cut] == 1).double().mean()),
+               "requested_lines_per_read": lines, "rank_blocks_per_read": loads["rank_blocks_16B"] / R,
+               "counting_pass_matches": bool(torch.equal(sp_c, sp) and torch.equal(ep_c, ep)),
+               "every_cut_read_found": bool((width[cut] > 0).all())}
+        if sa_h is not None:
+            # bit-exact against the oracle's loc_search / locate on a sample, on the index the oracle derives
+            # from the suffix array compared with csuff_arr above
+            fo = orc.make_fmi(text, n, sa_h)
+            S = 20_000
+            pick = torch.arange(0, R, R // S, device="cuda")[:S]
+            reads_h = d_reads[: R * m].view(R, m)[pick].cpu().numpy()
+            sp_o, ep_o = orc.search_batch(fo, reads_h, m, m, S)
+            sp_g, ep_g, pos_g = (G.to_numpy_u32(x[pick]) for x in (sp, ep, pos))
+            found = ep_o > sp_o
+            pos_o, _ = orc.locate_rows(fo, np.where(found, sp_o, 0).astype(np.uint32))
+            leg["sample_matches_oracle"] = bool((sp_g == sp_o).all() and (ep_g == ep_o).all()
+                                                and (pos_g[found] == pos_o[found]).all())
+            leg["sample"] = f"{S} reads, oracle loc_search + unc_sa of the first row"
+            del fo
+        # the same batch on rank blocks alone
+        ix.compact()
+        sp2, ep2, lr2 = ix.search(d_reads, m, R, want_locrow=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            ix.search(d_reads, m, R, want_locrow=True, out=(sp2, ep2, lr2))
+        torch.cuda.synchronize()
+        ro = (time.perf_counter() - t0) / 2
+        leg["rank_only"] = {"value": R / ro, "unit": "reads/s", "ms_per_step": ro * 1e3,
+                            "same_intervals": bool(torch.equal(sp2, sp) and torch.equal(ep2, ep))}
+        out["search"] = leg
+        ix.close()
+        del d_reads, d_offs, sp, ep, pos, sp2, ep2, lr2
+    except Exception as e:  # noqa: BLE001 - the build figure does not depend on this
+        out["search"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    del d_text
     G._lib.load().bwtgpu_release_cache()
     return out
 
@@ -409,6 +482,7 @@ def main():
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the 3.1 Gbp / 100 M x 100 bp leg of the default line (c2, one GPU)")
     ap.add_argument("--c4-steps", type=int, default=5, help="timed steps of that leg")
+    ap.add_argument("--c5-steps", type=int, default=5, help="timed search steps on the tandem-repeat text")
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
     ap.add_argument("--no-cpu", action="store_true")

@@ -203,3 +203,50 @@ def test_largest_text_the_32_bit_rows_allow(gpu):
     ix.close()
     gpu._lib.load().bwtgpu_release_cache()
 
+
+
+def test_search_on_100_mbp_tandem_repeat(oracle, gpu):
+    """10 M x 50 bp reads cut from the mutated period-1000 repeat: nearly every read occurs thousands of
+    times, so intervals stay wide to the last base and the search goes on with rank steps where it
+    compares with the text on a random genome (seqindex.c:298-306).  Intervals and the position of the
+    first row bit-exact against the oracle on a sample; every cut read found with its own row inside its
+    interval; both index forms equal on all reads."""
+    n, R, m = 100_000_000, 10_000_000, 50
+    text = synth.gen_tandem(n, 1000, 11, 5000, 3)
+    d_text = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
+    sa = gpu.sa_build(d_text, n)
+    sa_h = gpu.to_numpy_u32(sa)
+    assert gpu.sa_certify(d_text, n, sa) == (0, 0, 0)
+    del sa
+    ix = gpu.build_index_dev(d_text, n)
+    d_reads, d_offs = gpu.gen_reads(d_text, n, R, m, synth.READS_SEED + 50)
+    sp, ep, pos = ix.search_locate(d_reads, m, R)
+    sp_h, ep_h, pos_h, offs = (gpu.to_numpy_u32(x) for x in (sp, ep, pos, d_offs))
+    cut = offs != 0xFFFFFFFF
+    assert np.all(ep_h[cut] > sp_h[cut])
+    assert np.median((ep_h - sp_h)[cut]) > 100  # a repeat: reads occur many times
+    # the row of the offset a read was cut at lies inside its interval
+    pick = np.flatnonzero(cut)[:: 97]
+    isa = np.empty(n + 1, np.uint32)
+    isa[sa_h] = np.arange(n + 1, dtype=np.uint32)
+    rows = isa[offs[pick]]
+    assert np.all((sp_h[pick] <= rows) & (rows < ep_h[pick]))
+    del isa
+    # locate() = the suffix of the interval's first row
+    np.testing.assert_array_equal(pos_h[pick], sa_h[sp_h[pick]])
+    # the oracle's loc_search on a sample, on the index it derives from this suffix array
+    fo = oracle.make_fmi(text, n, sa_h)
+    S = np.arange(0, R, 499)
+    reads_h = d_reads[: R * m].view(R, m)[torch.from_numpy(S).cuda()].cpu().numpy()
+    sp_o, ep_o = oracle.search_batch(fo, reads_h, m, m, len(S))
+    np.testing.assert_array_equal(sp_h[S], sp_o)
+    np.testing.assert_array_equal(ep_h[S], ep_o)
+    found = ep_o > sp_o
+    pos_o, _ = oracle.locate_rows(fo, np.where(found, sp_o, 0).astype(np.uint32))
+    np.testing.assert_array_equal(pos_h[S][found], pos_o[found])
+    # rank blocks alone: the same intervals for all reads
+    ix.compact()
+    sp2, ep2 = ix.search(d_reads, m, R)
+    assert torch.equal(sp2, sp) and torch.equal(ep2, ep)
+    ix.close()
+    gpu._lib.load().bwtgpu_release_cache()
