@@ -682,8 +682,41 @@ def main():
                                          "unit": "GB/s", "frac": 5.625 * nn / t_max / 1e9 / (HBM_PEAK_GBS * world)}}
             return res
 
+        def exchange_probe():
+            """Measured bandwidth of the two collectives a sharded build could use: an all-gather
+            (what it uses) and an all-to-all (the id exchange it does not), 64 MB per rank."""
+            per = 64 << 20
+            dev = "cpu" if os.environ.get("BWT_BENCH_REHEARSAL") else "cuda"
+            if dev == "cpu":
+                per = 4 << 20
+            per -= per % world
+            src = torch.ones(per, dtype=torch.uint8, device=dev)
+            gathered = torch.empty(per * world, dtype=torch.uint8, device=dev)
+            dealt = torch.empty(per, dtype=torch.uint8, device=dev)
+            res = {"bytes_per_rank": per}
+            for name, fn in (("all_gather", lambda: dist.all_gather_into_tensor(gathered, src)),
+                             ("all_to_all", lambda: dist.all_to_all_single(dealt, src))):
+                phase["at"] = f"exchange probe: {name}"
+                try:
+                    fn()
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        fn()
+                    barrier()
+                    dtp = (time.perf_counter() - t0) / 5
+                    tt = torch.tensor([dtp], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    recv = per * (world - 1) if name == "all_gather" else per * (world - 1) // world
+                    res[name] = {"ms": float(tt.item()) * 1e3, "received_bytes_per_rank": recv,
+                                 "gb_per_s_per_rank": recv / float(tt.item()) / 1e9}
+                except Exception as e:  # noqa: BLE001 - a probe
+                    res[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            return res
+
         try:
             out = one_text(d_text, n, ix, "")
+            out["exchange_probe"] = exchange_probe()
             out["what"] = ("text replicated; each rank sorts one bucket range and the ranks all-gather 0.75 B/base "
                            "of index products over RCCL (index); then 4 B/base of rows for the position records "
                            "(index_and_suffix_array)")

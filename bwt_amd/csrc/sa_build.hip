@@ -2327,7 +2327,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     unsigned long long *d_range = reinterpret_cast<unsigned long long *>(ws + L.range);
     if (src_id == kSrcImplicit) {
       if (range) BWT_HIP(hipMemsetAsync(d_range, 0, kRangeBytes + 16, s));
-      BWT_LAUNCH("sa_part_hist", k_part_hist0, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, n, ctr, counts, dlo,
+      BWT_LAUNCH("sa_part_hist_l0", k_part_hist0, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, n, ctr, counts, dlo,
                  dhi, range ? d_range : (unsigned long long *)nullptr);
     } else if (levels == 1) {
       // level 0 stored words that start with this level's four bases
