@@ -35,6 +35,7 @@ constexpr int kScat1Threads = 1024;                    // scatter of the levels 
 constexpr int kScat1Items = kPartTile / kScat1Threads;
 constexpr int kHistItems = kPartTile / kPartThreads;
 constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
+constexpr uint32_t kWaveLeafMax = 768;                // ... and one wave on its own: small children are merged up to this
 constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
 constexpr uint32_t kMaxDepth = 24;                    // bucket levels stop here; doubling takes over
 constexpr uint32_t kLeafKeyBases = 15;                // bases in a leaf sort key
@@ -61,6 +62,8 @@ struct Counters {
   uint32_t active;      // doubling: rows still in groups
   uint32_t endloc;      // SA row whose suffix starts at 0 (the $ of the BWT)
   uint32_t ncur;        // segments of the level being partitioned (k_begin_level)
+  uint32_t nbig;        // leaves of more than kWaveLeafMax rows (listed for the workgroup-wide leaf sort)
+  uint32_t ndeferred;   // leaves the one-wave leaf sort left to the workgroup-wide one when it met them
 };
 
 // ---- text -------------------------------------------------------------
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256)
 k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
                 uint32_t dst_id /* leaf_src_word */, Seg *__restrict__ next_segs, uint32_t next_cap,
                 Leaf *__restrict__ leaves, uint32_t leaf_cap, uint32_t *__restrict__ leafmask,
-                Counters *__restrict__ ctr, int by_eighth) {
+                Counters *__restrict__ ctr, int by_eighth, uint32_t *__restrict__ bigleaves) {
   // by_eighth (level 0, one segment): seg_counts holds eight rows of counts, one
   // per eighth of the tiles; each becomes that eighth's own run of cursors
   // inside every child, so that what one XCD scatters lies together.
@@ -335,18 +338,33 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   if (big) {
     sidx[upto_[t] >> kRowsBits] = t;
   } else {
-    // the furthest child e such that children t..e are small and hold at most kLeafMax rows
+    // the furthest child e such that children t..e are small and hold at most kWaveLeafMax rows
+    // (a wave sorts such a leaf by itself); a child of more than that is a leaf of its own
     const uint32_t from = upto_[t];
     uint32_t lo = t, hi = 255;
     while (lo < hi) {
       const uint32_t mid = (lo + hi + 1) >> 1, upto = upto_[mid + 1];
-      if ((upto >> kRowsBits) == (from >> kRowsBits) && upto - from <= kLeafMax) lo = mid;
+      if ((upto >> kRowsBits) == (from >> kRowsBits) && upto - from <= kWaveLeafMax) lo = mid;
       else hi = mid - 1;
     }
     reach[t] = lo;
   }
-  __syncthreads();
-  if (!big && (t == 0 || sizes[t - 1] > kLeafMax)) {
+  // (no neighbours to merge at all -- every two small children together exceed a wave's leaf, the
+  // usual case one level above the leaves -- is settled without the walk: each child is a leaf)
+  const bool alone = big || reach[t] == t;
+  if (__syncthreads_and(alone)) {
+    const bool is_leaf = !big && c != 0;
+    const uint64_t mine = __ballot(is_leaf);
+    if (lane == 0) wtot[wave] = (uint32_t)__popcll(mine);
+    __syncthreads();
+    uint32_t k = (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; ++w) k += wtot[w];
+    if (is_leaf) {
+      lstart[k] = start;
+      lsize[k] = c;
+    }
+    if (t == 255) nl = k + (is_leaf ? 1u : 0u);
+  } else if (!big && (t == 0 || sizes[t - 1] > kLeafMax)) {
     uint32_t d = t;
     while (d < 256 && sizes[d] <= kLeafMax) {
       const uint32_t e = reach[d];
@@ -368,7 +386,11 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
     if (lbase + l > leaf_cap || sbase + g > next_cap) ctr->overflow = 1;
   }
   __syncthreads();
-  if (t < nl && lbase + t < leaf_cap) leaves[lbase + t] = Leaf{lstart[t], lsize[t], depth, dst_id};
+  if (t < nl && lbase + t < leaf_cap) {
+    leaves[lbase + t] = Leaf{lstart[t], lsize[t], depth, dst_id};
+    // more rows than one wave sorts: on the list of the workgroup-wide leaf sort
+    if (lsize[t] > kWaveLeafMax) bigleaves[atomicAdd(&ctr->nbig, 1u)] = lbase + t;
+  }
   if (t < ns && sbase + t < next_cap) next_segs[sbase + t] = Seg{starts[sidx[t]], sizes[sidx[t]]};
 }
 
@@ -1021,18 +1043,15 @@ __device__ __forceinline__ int deep_cmp(const uint32_t *__restrict__ tb, uint32_
 // descending), settles short runs of equal keys by comparing the suffixes
 // further, writes the rows of the suffix array, and records for every row the
 // first row of its tie group (its own row when resolved).
-__global__ void __launch_bounds__(kLeafThreads, 2)
-k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
-            const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
-            const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
-            uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
-            uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
-            uint8_t *__restrict__ leaf_ties /* per leaf: 1 if it wrote tie-group heads */,
-            uint32_t *__restrict__ samples /* SA[8 i] at samples[i], or null */,
-            Counters *__restrict__ ctr, uint32_t first_leaf) {
-  // the grid may be sized by a guess made before the host knew the number of leaves
-  const uint32_t leaf = first_leaf + blockIdx.x;
-  if (leaf >= ctr->nleaves) return;
+__device__ __forceinline__ void
+leaf_sort_block(const uint32_t leaf, const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+                const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+                const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
+                uint32_t *__restrict__ sa_rows /* = SA+1 */, uint32_t *__restrict__ ghead /* full rows */,
+                uint8_t *__restrict__ bw /* BWT symbol of each row of SA+1 */,
+                uint8_t *__restrict__ leaf_ties /* per leaf: 1 if it wrote tie-group heads */,
+                uint32_t *__restrict__ samples /* SA[8 i] at samples[i], or null */,
+                Counters *__restrict__ ctr) {
   __shared__ uint64_t keys[kLeafMax + kLeafMax / 32 + 1];
   __shared__ uint32_t settled[kLeafMax / 32];  // bit j: row j is ordered against row j-1
   __shared__ uint32_t wred[kLeafWaves], wmax[kLeafWaves];
@@ -1235,6 +1254,395 @@ k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
     if (ties) ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
     bw[start + j] = (uint8_t)(o >> 44);
   }
+}
+
+// The leaves of more than kWaveLeafMax rows (listed by k_part_classify): one workgroup each.
+__global__ void __launch_bounds__(kLeafThreads, 2)
+k_leaf_sort(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+            const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+            const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
+            uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
+            uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
+            const uint32_t *__restrict__ list, uint32_t first) {
+  if (first + blockIdx.x >= ctr->nbig) return;
+  leaf_sort_block(list[first + blockIdx.x], tb, bufA, bufB, keyA, keyB, leaves, n, sa_rows, ghead, bw, leaf_ties,
+                  samples, ctr);
+}
+
+// The leaves the one-wave sort below left to a whole workgroup when it met them
+// (keys so uneven that a counting bucket overflowed: repeats): how many is known
+// on the device only, so the workgroups take them from the list in turn.
+__global__ void __launch_bounds__(kLeafThreads)
+k_leaf_sort_deferred(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+                     const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+                     const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
+                     uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
+                     uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
+                     const uint32_t *__restrict__ deferred) {
+  const uint32_t count = ctr->ndeferred;
+  for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+    leaf_sort_block(deferred[i], tb, bufA, bufB, keyA, keyB, leaves, n, sa_rows, ghead, bw, leaf_ties, samples, ctr);
+    __syncthreads();  // the next leaf reuses the LDS
+  }
+}
+
+// ---- a leaf per wave ---------------------------------------------------------
+//
+// The workgroup-wide sort above spends most of its time waiting: ten phases
+// separated by barriers of eight waves, three workgroups to a CU.  A leaf of up
+// to kWaveLeafMax rows is sorted here by ONE wave with the same steps --
+// interpolation buckets, a place inside the bucket by counting, the tie groups
+// of neighbouring equal keys -- but no barrier at all: the lanes of a wave run in
+// lockstep, so an LDS write is visible to the wave's next LDS read (wave_sync
+// keeps the compiler from moving one across the other).  Sixteen waves to a CU,
+// each on a leaf of its own and at a phase of its own, keep the LDS and the
+// vector units busy while others wait for their loads.  The kernel is bound by
+// instruction issue, so the sort proper is compiled for 4, 8, 12 and 16 rows a
+// lane (a leaf takes the smallest that holds it) and only the last four rows of
+// a lane are ever tested against the leaf's end.
+constexpr int kWavePer = kWaveLeafMax / 64;    // rows a lane owns, at most
+constexpr uint32_t kWaveBuckets = 512;         // 16-bit counters, two per word
+constexpr uint32_t kWaveBucketMax = 32;        // a fuller bucket sends the leaf to the workgroup-wide sort
+constexpr int kWaveGroup = 1;                  // leaves (waves) per workgroup: a wave's LDS is free for the next leaf the moment it ends
+// counters: kWaveBuckets / 2 words, then the word that says where a bucket past the last would start,
+// then (two words on) the word that takes the increments of slots past the leaf's end
+constexpr uint32_t kWaveCntWords = kWaveBuckets / 2 + 4;
+constexpr uint32_t kWaveDummyCnt = kWaveBuckets / 2 + 2;
+// words: the rows, kWaveBucketMax sentinels behind the last row, and one slot for the words of slots past the end
+constexpr uint32_t kWaveDummyKey = kWaveLeafMax + kWaveBucketMax + 8;
+constexpr uint32_t kWaveKeySlots = kWaveDummyKey + 8;
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct WaveLeaf {
+  uint32_t leaf, size, start, depth, keybases;
+  const uint32_t *src, *srckey;
+};
+
+// Sorts the leaf's words into keys[0 .. size).  Returns 0 when a bucket
+// overflowed (nothing written that matters), 2 when two neighbouring rows have
+// equal keys (the caller settles the tie groups from the sorted words), and 1
+// when every key is distinct: the rows, their BWT symbols and samples have then
+// been written.  size in (64 (E - 4), 64 E].
+template <int E>
+__device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t *__restrict__ tb, uint64_t *keys,
+                                              uint32_t *cnt, uint32_t lane, uint32_t *__restrict__ sa_rows,
+                                              uint8_t *__restrict__ bw, uint32_t *__restrict__ samples,
+                                              Counters *__restrict__ ctr) {
+  const uint32_t size = L.size, start = L.start;
+  uint64_t r[E];
+  bool ok[4];  // whether the lane's last four slots are rows of the leaf; the others always are
+  auto row_of = [&](int m) { return 4u * ((uint32_t)(m / 4) * 64u + lane) + (uint32_t)(m % 4); };
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ok[e] = row_of(E - 4 + e) < size;
+  auto valid = [&](int m) { return m < E - 4 ? true : ok[m - (E - 4)]; };
+  typedef uint32_t u32x4_at_4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+  for (int u = 0; u < E / 4; ++u) {
+    const uint32_t j0 = row_of(4 * u);
+    if (L.src && (u < E / 4 - 1 || ok[3])) {
+      const u32x4_at_4 k4 = *reinterpret_cast<const u32x4_at_4 *>(L.srckey + start + j0);
+      const u32x4_at_4 i4 = *reinterpret_cast<const u32x4_at_4 *>(L.src + start + j0);
+      r[4 * u] = leaf_word(k4.x, i4.x);
+      r[4 * u + 1] = leaf_word(k4.y, i4.y);
+      r[4 * u + 2] = leaf_word(k4.z, i4.z);
+      r[4 * u + 3] = leaf_word(k4.w, i4.w);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        r[4 * u + e] = j0 + e < size ? leaf_fetch(tb, L.src, L.srckey, start + j0 + e, L.depth) : ~0ull;
+    }
+  }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t k = word_key(r[m]);
+    const uint32_t klo = valid(m) ? k : 0xFFFFFFFFu, khi = valid(m) ? k : 0u;
+    kmin = klo < kmin ? klo : kmin;
+    kmax = khi > kmax ? khi : kmax;
+  }
+  for (int off = 32; off; off >>= 1) {
+    const uint32_t a = __shfl_xor(kmin, off, 64), b = __shfl_xor(kmax, off, 64);
+    kmin = a < kmin ? a : kmin;
+    kmax = b > kmax ? b : kmax;
+  }
+  reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(0, 0, 0, 0);
+  // Words behind the last row that compare above every word: the count of smaller words
+  // below runs a fixed number of places on from a bucket's start, past its end
+  if (lane < kWaveBucketMax) keys[size + lane] = ~0ull;
+  wave_sync();
+  // counting pass: bucket by interpolation between the smallest and the largest key
+  const float scale = (float)kWaveBuckets / (float)(kmax - kmin + 1u);
+  uint32_t at[E];  // bucket | place among the bucket's words << 16, then the word's place in the leaf
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    uint32_t b = (uint32_t)((float)(word_key(r[m]) - kmin) * scale);
+    b = b < kWaveBuckets ? b : kWaveBuckets - 1;
+    const uint32_t sh = 16u * (b & 1u);
+    const uint32_t word = valid(m) ? b >> 1 : kWaveDummyCnt;
+    at[m] = b | ((atomicAdd(&cnt[word], 1u << sh) >> sh) << 16);
+  }
+  wave_sync();
+  uint32_t fullest = 0;
+  {
+    // exclusive scan of the bucket counts; lane l owns buckets [8 l, 8 l + 8)
+    const uint4 q = reinterpret_cast<const uint4 *>(cnt)[lane];
+    const uint32_t own[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16,
+                             q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+    uint32_t sum = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      sum += own[b];
+      fullest = own[b] > fullest ? own[b] : fullest;
+    }
+    uint32_t v = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = __shfl_up(v, off, 64);
+      if (lane >= off) v += u;
+    }
+    for (int off = 32; off; off >>= 1) {
+      const uint32_t u = __shfl_xor(fullest, off, 64);
+      fullest = u > fullest ? u : fullest;
+    }
+    fullest = __builtin_amdgcn_readfirstlane(fullest);
+    if (fullest > kWaveBucketMax) return 0;
+    uint32_t run = v - sum, w4[4];
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) {
+      w4[b / 2] = run | ((run + own[b]) << 16);  // start rows of the two buckets (<= 1024)
+      run += own[b] + own[b + 1];
+    }
+    reinterpret_cast<uint4 *>(cnt)[lane] = make_uint4(w4[0], w4[1], w4[2], w4[3]);  // a lane's own words: no one else's
+  }
+  wave_sync();
+  // the words go to their bucket in arrival order; at[] becomes the place of the bucket's first word
+#pragma unroll
+  for (int m = 0; m < E; ++m) {
+    const uint32_t b = at[m] & 0xFFFFu;
+    const uint32_t s0 = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+    keys[valid(m) ? s0 + (at[m] >> 16) : kWaveDummyKey] = r[m];
+    at[m] = s0;
+  }
+  wave_sync();
+  // Order inside the buckets: every word counts the smaller words among the `fullest`
+  // (the fullest bucket's count) words from its bucket's start on.  Words are distinct
+  // (they hold the suffix start) and those of later buckets, like the sentinels behind
+  // the last row, are larger: they count for nothing.
+  uint32_t rank[E];
+#pragma unroll
+  for (int m = 0; m < E; ++m) rank[m] = 0;
+#pragma unroll 2
+  for (uint32_t i = 0; i < fullest; ++i) {
+#pragma unroll
+    for (int m = 0; m < E; ++m) rank[m] += keys[at[m] + i] < r[m] ? 1u : 0u;
+  }
+  wave_sync();
+#pragma unroll
+  for (int m = 0; m < E; ++m) keys[valid(m) ? at[m] + rank[m] : kWaveDummyKey] = r[m];
+  wave_sync();
+  // sorted.  Row j = lane + 64 i: its neighbour j - 1 is the lane before (lane 63 of the round before)
+  bool any_equal = false;
+  uint32_t before = 0xFFFFFFFFu;  // key of row 64 i - 1; no key has 32 bits
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t j = lane + 64u * (uint32_t)i;
+    r[i] = (i < E - 4 || j < size) ? keys[j] : ~0ull;
+    const uint32_t k = word_key(r[i]);
+    const uint32_t up = __shfl_up(k, 1, 64);
+    const uint32_t prev = lane ? up : before;
+    any_equal = any_equal || (j < size && prev == k);
+    before = __shfl(k, 63, 64);
+  }
+  if (__ballot(any_equal)) return 2;
+  // every row is its own group
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const uint32_t j = lane + 64u * (uint32_t)i;
+    if (i < E - 4 || j < size) {
+      const uint32_t id = word_id(r[i]), row = start + j;
+      sa_rows[row] = id;
+      if (samples && !((1 + row) & kDevSampleMask)) samples[(1 + row) >> kDevSampleShift] = id;
+      bw[row] = (uint8_t)(r[i] & 3u);
+      if (id == 0) ctr->endloc = 1 + row;
+    }
+  }
+  return 1;
+}
+
+// One leaf, by the wave that calls it (every lane); keys / cnt: the wave's own LDS.
+__device__ __forceinline__ void
+wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *keys, uint32_t *cnt,
+          const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA, const uint32_t *__restrict__ bufB,
+          const uint32_t *__restrict__ keyA, const uint32_t *__restrict__ keyB, uint32_t n,
+          uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
+          uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
+          uint32_t *__restrict__ deferred) {
+  constexpr int E = kWavePer;
+  static_assert(E == 12 && kWaveBuckets / 2 == 4 * 64, "twelve rows, four counter words a lane");
+  WaveLeaf L;
+  L.leaf = leaf;
+  L.size = __builtin_amdgcn_readfirstlane(lf.size);
+  L.start = __builtin_amdgcn_readfirstlane(lf.start);
+  L.depth = __builtin_amdgcn_readfirstlane(lf.depth);
+  const uint32_t srcw = __builtin_amdgcn_readfirstlane(lf.src), srcid = srcw & 255u;
+  L.keybases = srcw >> 8;
+  L.src = srcid == kSrcA ? bufA : srcid == kSrcB ? bufB : nullptr;
+  L.srckey = srcid == kSrcA ? keyA : keyB;
+  const uint32_t size = L.size, start = L.start, depth = L.depth, keybases = L.keybases;
+  if (size > kWaveLeafMax) return;  // on the list of the workgroup-wide sort
+  if (size == 1) {
+    if (lane == 0) {
+      const uint64_t w = leaf_fetch(tb, L.src, L.srckey, start, depth);
+      const uint32_t id = word_id(w);
+      sa_rows[start] = id;
+      if (samples && !((1 + start) & kDevSampleMask)) samples[(1 + start) >> kDevSampleShift] = id;
+      leaf_ties[leaf] = 0;
+      bw[start] = (uint8_t)(w & 3u);
+      if (id == 0) ctr->endloc = 1 + start;
+    }
+    return;
+  }
+  int how;
+  if (size <= 256) how = wave_leaf_sort<4>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  else if (size <= 512) how = wave_leaf_sort<8>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  else how = wave_leaf_sort<12>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  if (how == 0) {
+    if (lane == 0) deferred[atomicAdd(&ctr->ndeferred, 1u)] = leaf;
+    return;
+  }
+  if (how == 1) {
+    if (lane == 0) leaf_ties[leaf] = 0;
+    return;
+  }
+  // ---- neighbouring rows with equal keys: the tie groups, from the sorted words.
+  // Blocked: lane l owns rows [l per, l per + per)
+  uint32_t *settled = cnt;  // bit j: row j is ordered against row j-1 (the counters are done with)
+  wave_sync();
+  if (lane < kWaveLeafMax / 32) settled[lane] = 0;
+  wave_sync();
+  const uint32_t per = (size + 63u) / 64u;  // 1 .. kWavePer
+  const uint32_t j0 = lane * per;
+  uint64_t w[E + 2];  // the lane's rows and one neighbour on each side: w[1 + k] is row j0 + k
+  // short runs of equal keys: the lane that owns the first row of a run orders the
+  // whole run by comparing the suffixes beyond the key
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t j = j0 + k;
+    if (j + 1 >= size) break;
+    const uint32_t key = word_key(keys[j]);
+    if (word_key(keys[j + 1]) != key) continue;
+    if (j > 0 && word_key(keys[j - 1]) == key) continue;
+    uint32_t e = j + 2;
+    while (e < size && e - j <= kDeepRun && word_key(keys[e]) == key) ++e;
+    if (e - j > kDeepRun) continue;
+    bool ok = true;
+    for (uint32_t a = j + 1; a < e && ok; ++a) {
+      const uint64_t v = keys[a];
+      uint32_t b = a;
+      while (b > j) {
+        const int c = deep_cmp(tb, n, word_id(v), word_id(keys[b - 1]), depth + keybases);
+        if (c == 0) ok = false;
+        if (c >= 0) break;
+        keys[b] = keys[b - 1];
+        --b;
+      }
+      keys[b] = v;
+    }
+    if (ok)
+      for (uint32_t a = j + 1; a < e; ++a) atomicOr(&settled[a >> 5], 1u << (a & 31u));
+  }
+  wave_sync();
+#pragma unroll
+  for (uint32_t k = 0; k < (uint32_t)E + 2; ++k) {
+    const uint32_t j = j0 + k - 1u;  // wraps below row 0, which then fails j < size
+    w[k] = (k <= per + 1 && j < size) ? keys[j] : ~0ull;
+  }
+  uint32_t hv[E];
+  uint32_t local_max = 0, tied_rows = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < (uint32_t)E; ++k) {
+    hv[k] = 0;
+    const uint32_t j = j0 + k;
+    if (k < per && j < size) {
+      bool tie = false, tie_next = false;
+      const uint64_t cur = w[k + 1];
+      if (j > 0) {
+        const uint64_t prv = w[k];
+        const uint32_t pid = word_id(prv);
+        // the previous suffix is final here if its key window ran past the
+        // end of the text: a shorter suffix precedes every longer one it ties
+        tie = word_key(prv) == word_key(cur) &&
+              (uint64_t)pid + depth + keybases < n && !((settled[j >> 5] >> (j & 31u)) & 1u);
+      }
+      if (j + 1 < size) {
+        const uint64_t nxt = w[k + 2];
+        const uint32_t cid = word_id(cur);
+        tie_next = word_key(nxt) == word_key(cur) &&
+                   (uint64_t)cid + depth + keybases < n &&
+                   !((settled[(j + 1) >> 5] >> ((j + 1) & 31u)) & 1u);
+      }
+      hv[k] = tie ? 0u : 1u + start + j;
+      tied_rows += (tie || tie_next) ? 1u : 0u;
+      local_max = hv[k] > local_max ? hv[k] : local_max;
+    }
+  }
+  // inclusive max-scan of local_max over the lanes
+  uint32_t v = local_max;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v = u > v ? u : v;
+  }
+  uint32_t tr = tied_rows;
+  for (int off = 32; off; off >>= 1) tr += __shfl_xor(tr, off, 64);
+  const uint32_t up = __shfl_up(v, 1, 64);
+  uint32_t run = lane ? up : 0u;  // max over all earlier lanes
+  if (lane == 0 && tr) {
+    atomicAdd(&ctr->unresolved, tr);
+    atomicMin(&ctr->min_depth, depth + keybases);
+  }
+  wave_sync();  // neighbours' keys have been read; the LDS slots are reused below
+#pragma unroll
+  for (uint32_t k = 0; k < (uint32_t)E; ++k) {
+    const uint32_t j = j0 + k;
+    if (k < per && j < size) {
+      const uint64_t cur = w[k + 1];
+      const uint32_t id = word_id(cur);
+      run = hv[k] > run ? hv[k] : run;
+      // head row relative to the leaf, BWT symbol, id: one word per row
+      keys[j] = ((uint64_t)(cur & 3u) << 44) | ((uint64_t)(run - (1 + start)) << 32) | id;
+      if (id == 0) ctr->endloc = 1 + start + j;
+    }
+  }
+  wave_sync();
+  if (lane == 0) leaf_ties[leaf] = 1;
+  for (uint32_t j = lane; j < size; j += 64) {
+    const uint64_t o = keys[j];
+    sa_rows[start + j] = (uint32_t)o;
+    if (samples && !((1 + start + j) & kDevSampleMask)) samples[(1 + start + j) >> kDevSampleShift] = (uint32_t)o;
+    ghead[1 + start + j] = 1 + start + ((uint32_t)(o >> 32) & 0xFFFu);
+    bw[start + j] = (uint8_t)(o >> 44);
+  }
+}
+
+__global__ void __launch_bounds__(64 * kWaveGroup) __attribute__((amdgpu_waves_per_eu(5, 5)))
+k_leaf_sort_wave(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+                 const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+                 const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
+                 uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
+                 uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
+                 uint32_t first_leaf, uint32_t *__restrict__ deferred) {
+  __shared__ uint64_t keys_all[kWaveGroup][kWaveKeySlots];
+  __shared__ uint32_t cnt_all[kWaveGroup][kWaveCntWords];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t leaf = first_leaf + blockIdx.x * kWaveGroup + wv;
+  // the grid may be sized by a guess made before the host knew the number of leaves
+  if (leaf >= ctr->nleaves) return;
+  wave_leaf(leaf, leaves[leaf], lane, keys_all[wv], cnt_all[wv], tb, bufA, bufB, keyA, keyB, n, sa_rows, ghead, bw,
+            leaf_ties, samples, ctr, deferred);
 }
 
 // Before prefix doubling: every row of a leaf that found no ties is its own group.
@@ -2164,7 +2572,7 @@ static int sa_doubling_groups(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint3
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, ctr, scanws, range, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, bigleaves, deferred, ctr, scanws, range, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -2193,6 +2601,8 @@ static Layout layout_for(uint32_t n) {
   L.tile_first = take(((size_t)L.seg_cap + 1) * 4);
   L.leaves = take((size_t)L.leaf_cap * sizeof(Leaf));
   L.leaf_ties = take((size_t)L.leaf_cap);
+  L.bigleaves = take((size_t)L.leaf_cap * 4);
+  L.deferred = take((size_t)L.leaf_cap * 4);
   L.ctr = take(sizeof(Counters));
   L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
   L.range = take(kRangeBytes + 16);
@@ -2250,6 +2660,8 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   uint32_t *tile_first = reinterpret_cast<uint32_t *>(ws + L.tile_first);
   Leaf *leaves = reinterpret_cast<Leaf *>(ws + L.leaves);
   uint8_t *leaf_ties = ws + L.leaf_ties;
+  uint32_t *bigleaves = reinterpret_cast<uint32_t *>(ws + L.bigleaves);
+  uint32_t *deferred = reinterpret_cast<uint32_t *>(ws + L.deferred);
   Counters *ctr = reinterpret_cast<Counters *>(ws + L.ctr);
   void *scanws = ws + L.scanws;
   const size_t scanws_bytes = scan_workspace_bytes(L.seg_cap + 1);
@@ -2268,13 +2680,18 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
 
   uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
   int cur = 0;
-  uint32_t nleaves_host = 0;
+  uint32_t nleaves_host = 0, nbig_host = 0;
   if (n <= kLeafMax) {
     const Leaf whole = {0, n, 0, leaf_src_word(kSrcImplicit, kLeafKeyBases)};
     BWT_HIP(hipMemcpyAsync(leaves, &whole, sizeof whole, hipMemcpyHostToDevice, s));
     const uint32_t one = 1;
     BWT_HIP(hipMemcpyAsync(&ctr->nleaves, &one, 4, hipMemcpyHostToDevice, s));
     nleaves_host = 1;
+    if (n > kWaveLeafMax) {
+      BWT_HIP(hipMemsetAsync(bigleaves, 0, 4, s));  // leaf 0
+      BWT_HIP(hipMemcpyAsync(&ctr->nbig, &one, 4, hipMemcpyHostToDevice, s));
+      nbig_host = 1;
+    }
   } else {
     const Seg whole = {0, n};
     BWT_HIP(hipMemcpyAsync(segs[0], &whole, sizeof whole, hipMemcpyHostToDevice, s));
@@ -2362,7 +2779,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
-               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0);
+               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0, bigleaves);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, n, dst,
                  dstkey, ctr, counts, leafmask, dlo, dhi);
@@ -2391,9 +2808,9 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       // many as this guess, the rest (if any) after the last level.
       BWT_HIP(hipMemcpyAsync(extras->readback, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
       BWT_HIP(hipEventRecord(ahead.ev, s));
-      const uint32_t guess = n / (kLeafMax * 3 / 4) + 1;
-      BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(guess), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
-                 leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, 0u);
+      const uint32_t guess = (n / 512 + kWaveGroup) / kWaveGroup * kWaveGroup;
+      BWT_LAUNCH("sa_leaf_sort", k_leaf_sort_wave, dim3(guess / kWaveGroup), dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB,
+                 keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, 0u, deferred);
       BWT_HIP(hipEventSynchronize(ahead.ev));
       std::memcpy(&h_ctr, extras->readback, sizeof h_ctr);
       leaves_sorted = h_ctr.nleaves < guess ? h_ctr.nleaves : guess;
@@ -2404,6 +2821,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     if (h_ctr.overflow) return set_error(kErrInternal, "SA build: bucket list overflow at depth %u", depth - kDigitBases);
     nsegs = h_ctr.nnext;
     nleaves_host = h_ctr.nleaves;
+    nbig_host = h_ctr.nbig;
     exact = true;
   }
   if (!exact) return set_error(kErrInternal, "SA build: level count not read back");
@@ -2411,8 +2829,19 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   g_stats.v[1] = nleaves_host;
   g_stats.v[4] = depth;
   if (nleaves_host > leaves_sorted)
-    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort, dim3(nleaves_host - leaves_sorted), dim3(kLeafThreads), 0, s, tb, bufA,
-               bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, leaves_sorted);
+    BWT_LAUNCH("sa_leaf_sort", k_leaf_sort_wave, dim3((unsigned)div_up(nleaves_host - leaves_sorted, kWaveGroup)),
+               dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples,
+               ctr, leaves_sorted, deferred);
+  if (nbig_host)
+    BWT_LAUNCH("sa_leaf_sort_big", k_leaf_sort, dim3(nbig_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
+               leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, bigleaves, 0u);
+  if (nleaves_host) {
+    // what the waves left to whole workgroups when they met it (lopsided keys): the count is on the device,
+    // zero for a text without repeats
+    const unsigned groups = nleaves_host < 512u ? nleaves_host : 512u;
+    BWT_LAUNCH("sa_leaf_sort_deferred", k_leaf_sort_deferred, dim3(groups), dim3(kLeafThreads), 0, s, tb, bufA, bufB,
+               keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, deferred);
+  }
   if (nsegs) {
     const uint32_t *src = src_id == kSrcA ? bufA : bufB;
     uint32_t *shortl = counts;  // the levels are done with their counters: 256 words a segment, 33 used
