@@ -84,6 +84,7 @@ SIGNATURES = {
     "bwtgpu_sa_certify": (C.c_int, [vp, u32, vp, vp, sz, C.POINTER(u64), vp]),
     "bwtgpu_index_certify": (C.c_int, [vp, vp, vp, sz, C.POINTER(u64), vp]),
     "bwtgpu_index_prepare_search": (C.c_int, [vp, vp]),
+    "bwtgpu_index_replicate": (vp, [vp, C.c_int]),
     "bwtgpu_index_attach_text": (C.c_int, [vp, vp, vp]),
     "bwtgpu_index_attach_text_dev": (C.c_int, [vp, vp, vp]),
     "bwtgpu_locate_workspace_bytes": (sz, []),

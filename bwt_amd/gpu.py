@@ -246,6 +246,10 @@ class GpuIndex:
         return dict(zip(("out_of_range", "not_a_permutation", "order", "bwt_blocks", "samples", "endloc"),
                         (int(x) for x in rep)))
 
+    def replicate(self, device):
+        """A copy of the index in the memory of GPU `device` (bwtgpu_index_replicate)."""
+        return GpuIndex(_lib.load().bwtgpu_index_replicate(self.h, int(device)))
+
     def prepare_search(self):
         """Make the search-only arrays now (see bwtgpu_index_prepare_search)."""
         check(_lib.load().bwtgpu_index_prepare_search(self.h, _stream()))

@@ -66,3 +66,39 @@ print("slots", L.fmi_device_slots())
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.strip().endswith(f"slots {want}"), out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["built", "built, searched", "loaded", "lean"])
+def test_a_replica_answers_like_its_source(oracle, gpu, form):
+    """bwtgpu_index_replicate (here onto the same GPU): the copy makes its own search-only arrays and gives
+    the source's intervals, rows and positions; it outlives the source."""
+    import numpy as np
+    import torch
+
+    from bwt_amd import synth
+
+    n, R, m = 250_003, 20_000, 36
+    text = oracle.gen_genome(n, synth.GENOME_SEED + 31)
+    fo = oracle.make_fmi(text, n)
+    if form.startswith("built"):
+        src = gpu.build_index(text, n)
+    else:
+        src = gpu.index_from_parts(fo.bwt, n, fo.endloc, fo.idxs, lean=form == "lean")
+    reads, _ = oracle.gen_reads(text, n, R, m, synth.READS_SEED + 31)
+    d = torch.from_numpy(np.concatenate([reads.reshape(-1), np.zeros(64, np.uint8)])).cuda()
+    if form == "built, searched":
+        src.search(d, m, R)
+    copy = src.replicate(0)
+    assert (copy.n, copy.endloc, copy.C) == (src.n, src.endloc, src.C)
+    want = [gpu.to_numpy_u32(x) for x in src.search_locate(d, m, R)]
+    src.close()
+    got = [gpu.to_numpy_u32(x) for x in copy.search_locate(d, m, R)]
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)
+    sp_o, ep_o = oracle.search_batch(fo, reads, m, m, R)
+    np.testing.assert_array_equal(got[0], sp_o)
+    np.testing.assert_array_equal(got[1], ep_o)
+    if form != "lean":
+        assert copy.device_bytes > 5 * n  # the copy has position records and a k-mer table of its own
+    copy.close()
