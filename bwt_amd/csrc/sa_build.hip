@@ -36,6 +36,7 @@ constexpr int kScat1Items = kPartTile / kScat1Threads;
 constexpr int kHistItems = kPartTile / kPartThreads;
 constexpr uint32_t kLeafMax = 4096;                   // suffixes one workgroup sorts in LDS
 constexpr uint32_t kWaveLeafMax = 768;                // ... and one wave on its own: small children are merged up to this
+constexpr uint32_t kWaveLeafMid = 1024;               // a child of up to this many rows is still one wave's (fewer waves to a CU)
 constexpr uint32_t kDigitBases = 4;                   // bases consumed per level (256 buckets)
 constexpr uint32_t kMaxDepth = 24;                    // bucket levels stop here; doubling takes over
 constexpr uint32_t kLeafKeyBases = 15;                // bases in a leaf sort key
@@ -62,7 +63,8 @@ struct Counters {
   uint32_t active;      // doubling: rows still in groups
   uint32_t endloc;      // SA row whose suffix starts at 0 (the $ of the BWT)
   uint32_t ncur;        // segments of the level being partitioned (k_begin_level)
-  uint32_t nbig;        // leaves of more than kWaveLeafMax rows (listed for the workgroup-wide leaf sort)
+  uint32_t nbig;        // leaves of more than kWaveLeafMid rows (listed for the workgroup-wide leaf sort)
+  uint32_t nmid;        // leaves of kWaveLeafMax + 1 .. kWaveLeafMid rows (listed for the one-wave sort with room for them)
   uint32_t ndeferred;   // leaves the one-wave leaf sort left to the workgroup-wide one when it met them
 };
 
@@ -264,7 +266,8 @@ __global__ void __launch_bounds__(256)
 k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts, uint32_t depth,
                 uint32_t dst_id /* leaf_src_word */, Seg *__restrict__ next_segs, uint32_t next_cap,
                 Leaf *__restrict__ leaves, uint32_t leaf_cap, uint32_t *__restrict__ leafmask,
-                Counters *__restrict__ ctr, int by_eighth, uint32_t *__restrict__ bigleaves) {
+                Counters *__restrict__ ctr, int by_eighth, uint32_t *__restrict__ bigleaves,
+                uint32_t *__restrict__ midleaves) {
   // by_eighth (level 0, one segment): seg_counts holds eight rows of counts, one
   // per eighth of the tiles; each becomes that eighth's own run of cursors
   // inside every child, so that what one XCD scatters lies together.
@@ -310,24 +313,34 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
     }
   }
   __syncthreads();
-  // Greedy merge of neighbouring small children into leaves.  A run of small children
-  // (between two large ones) is dealt by the thread of its first child; how far a leaf that
-  // starts at child d reaches is found by every thread for its own child at once (a binary
-  // search over prefix sums), so the walk is one hop per leaf, not one step per child.
-  __shared__ uint32_t lstart[256], lsize[256], sidx[256], upto_[257], reach[256], wtot[4];
+  // Greedy merge of neighbouring children into leaves.  Children come in four kinds: large ones
+  // (more than kLeafMax rows) go on to the next level; those of up to kWaveLeafMax rows are merged
+  // into leaves of up to that many rows, which one wave sorts by itself; one of up to kWaveLeafMid
+  // rows is a leaf of its own, also one wave's; the rest are merged into leaves of up to kLeafMax
+  // rows for the workgroup-wide sort.  A leaf holds children of one kind.
+  // A run of children between two large ones is dealt by the thread of its first child; how far
+  // a leaf that starts at child d reaches is found by every thread for its own child at once (a
+  // binary search over prefix sums), so the walk is one hop per leaf, not one step per child.
+  __shared__ uint32_t lstart[256], lsize[256], sidx[256], reach[256], wtot[4];
+  __shared__ uint64_t upto_[257], wtot64[4];
   __shared__ uint32_t nl, ns, lbase, sbase;
-  constexpr uint32_t kRowsBits = 22;  // 256 small children hold at most 2^20 rows
+  constexpr uint32_t kRowsBits = 24, kRunBits = 16;  // rows (at most 2^20), runs of one kind, large children
+  constexpr uint64_t kRowsMask = (1ull << kRowsBits) - 1ull;
   const bool big = c > kLeafMax;
+  auto kind_of = [](uint32_t rows) { return rows > kLeafMax ? 3u : rows > kWaveLeafMid ? 2u : rows > kWaveLeafMax ? 1u : 0u; };
+  const uint32_t kind = kind_of(c);
   {
-    // inclusive scan of (large children so far, rows in small children so far), packed
-    uint32_t pk = big ? (1u << kRowsBits) : c;
+    // inclusive scan of (large children so far, runs begun so far, rows in other children so far), packed
+    const uint32_t kind_before = t ? kind_of(sizes[t - 1]) : 3u;
+    uint64_t pk = (big ? 1ull << (kRowsBits + kRunBits) : (uint64_t)c) |
+                  ((uint64_t)((big || kind != kind_before) ? 1u : 0u) << kRowsBits);
     for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t u = __shfl_up(pk, off, 64);
+      const uint64_t u = __shfl_up(pk, off, 64);
       if (lane >= off) pk += u;
     }
-    if (lane == 63) wtot[wave] = pk;
+    if (lane == 63) wtot64[wave] = pk;
     __syncthreads();
-    for (uint32_t w = 0; w < wave; ++w) pk += wtot[w];
+    for (uint32_t w = 0; w < wave; ++w) pk += wtot64[w];
     upto_[t + 1] = pk;
     if (t == 0) {
       upto_[0] = 0;
@@ -336,15 +349,17 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   }
   __syncthreads();
   if (big) {
-    sidx[upto_[t] >> kRowsBits] = t;
+    sidx[(uint32_t)(upto_[t] >> (kRowsBits + kRunBits))] = t;
   } else {
-    // the furthest child e such that children t..e are small and hold at most kWaveLeafMax rows
-    // (a wave sorts such a leaf by itself); a child of more than that is a leaf of its own
-    const uint32_t from = upto_[t];
+    // the furthest child e such that children t..e belong to t's run and hold no more rows than a leaf of its kind may
+    const uint64_t run = upto_[t + 1] >> kRowsBits;  // runs (and large children) up to and including t's own
+    const uint32_t from = (uint32_t)(upto_[t] & kRowsMask);
+    const uint32_t most = kind == 0 ? kWaveLeafMax : kind == 1 ? kWaveLeafMid : kLeafMax;
     uint32_t lo = t, hi = 255;
     while (lo < hi) {
-      const uint32_t mid = (lo + hi + 1) >> 1, upto = upto_[mid + 1];
-      if ((upto >> kRowsBits) == (from >> kRowsBits) && upto - from <= kWaveLeafMax) lo = mid;
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      const uint64_t upto = upto_[mid + 1];
+      if ((upto >> kRowsBits) == run && (uint32_t)(upto & kRowsMask) - from <= most) lo = mid;
       else hi = mid - 1;
     }
     reach[t] = lo;
@@ -368,7 +383,7 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
     uint32_t d = t;
     while (d < 256 && sizes[d] <= kLeafMax) {
       const uint32_t e = reach[d];
-      const uint32_t rows_in = upto_[e + 1] - upto_[d];  // no large child between: the difference is rows alone
+      const uint32_t rows_in = (uint32_t)(upto_[e + 1] & kRowsMask) - (uint32_t)(upto_[d] & kRowsMask);
       if (rows_in) {
         const uint32_t k = atomicAdd(&nl, 1u);
         lstart[k] = starts[d];
@@ -379,17 +394,30 @@ k_part_classify(const Seg *__restrict__ segs, uint32_t *__restrict__ seg_counts,
   }
   __syncthreads();
   if (t == 0) {
-    const uint32_t l = nl, g = upto_[256] >> kRowsBits;
+    const uint32_t l = nl, g = (uint32_t)(upto_[256] >> (kRowsBits + kRunBits));
     ns = g;
     lbase = l ? atomicAdd(&ctr->nleaves, l) : 0u;
     sbase = g ? atomicAdd(&ctr->nnext, g) : 0u;
     if (lbase + l > leaf_cap || sbase + g > next_cap) ctr->overflow = 1;
   }
   __syncthreads();
-  if (t < nl && lbase + t < leaf_cap) {
-    leaves[lbase + t] = Leaf{lstart[t], lsize[t], depth, dst_id};
-    // more rows than one wave sorts: on the list of the workgroup-wide leaf sort
-    if (lsize[t] > kWaveLeafMax) bigleaves[atomicAdd(&ctr->nbig, 1u)] = lbase + t;
+  {
+    const bool mine = t < nl && lbase + t < leaf_cap;
+    const uint32_t rows = mine ? lsize[t] : 0u;
+    if (mine) leaves[lbase + t] = Leaf{lstart[t], rows, depth, dst_id};
+    // more rows than the plain one-wave sort takes: on the list of the roomier one, or of the
+    // workgroup-wide sort; one claim of room per wave and list (every leaf of a level may be listed)
+    auto list = [&](bool want, uint32_t *counter, uint32_t *out) {
+      const uint64_t such = __ballot(want);
+      if (!such) return;
+      const int first = __ffsll((long long)such) - 1;
+      uint32_t base = 0;
+      if ((int)lane == first) base = atomicAdd(counter, (uint32_t)__popcll(such));
+      base = __shfl(base, first, 64);
+      if (want) out[base + (uint32_t)__popcll(such & ((1ull << lane) - 1ull))] = lbase + t;
+    };
+    list(rows > kWaveLeafMid, &ctr->nbig, bigleaves);
+    list(rows > kWaveLeafMax && rows <= kWaveLeafMid, &ctr->nmid, midleaves);
   }
   if (t < ns && sbase + t < next_cap) next_segs[sbase + t] = Seg{starts[sidx[t]], sizes[sidx[t]]};
 }
@@ -1300,7 +1328,6 @@ k_leaf_sort_deferred(const uint32_t *__restrict__ tb, const uint32_t *__restrict
 // instruction issue, so the sort proper is compiled for 4, 8, 12 and 16 rows a
 // lane (a leaf takes the smallest that holds it) and only the last four rows of
 // a lane are ever tested against the leaf's end.
-constexpr int kWavePer = kWaveLeafMax / 64;    // rows a lane owns, at most
 constexpr uint32_t kWaveBuckets = 512;         // 16-bit counters, two per word
 constexpr uint32_t kWaveBucketMax = 32;        // a fuller bucket sends the leaf to the workgroup-wide sort
 constexpr int kWaveGroup = 1;                  // leaves (waves) per workgroup: a wave's LDS is free for the next leaf the moment it ends
@@ -1308,9 +1335,10 @@ constexpr int kWaveGroup = 1;                  // leaves (waves) per workgroup: 
 // then (two words on) the word that takes the increments of slots past the leaf's end
 constexpr uint32_t kWaveCntWords = kWaveBuckets / 2 + 4;
 constexpr uint32_t kWaveDummyCnt = kWaveBuckets / 2 + 2;
-// words: the rows, kWaveBucketMax sentinels behind the last row, and one slot for the words of slots past the end
-constexpr uint32_t kWaveDummyKey = kWaveLeafMax + kWaveBucketMax + 8;
-constexpr uint32_t kWaveKeySlots = kWaveDummyKey + 8;
+// words of a sort of up to `rows` rows: the rows, kWaveBucketMax sentinels behind the last row, and one
+// slot for the words of slots past the end
+constexpr uint32_t wave_dummy_key(uint32_t rows) { return rows + kWaveBucketMax + 8; }
+constexpr uint32_t wave_key_slots(uint32_t rows) { return wave_dummy_key(rows) + 8; }
 
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1328,7 +1356,7 @@ struct WaveLeaf {
 // equal keys (the caller settles the tie groups from the sorted words), and 1
 // when every key is distinct: the rows, their BWT symbols and samples have then
 // been written.  size in (64 (E - 4), 64 E].
-template <int E>
+template <int E, uint32_t DUMMY /* wave_dummy_key of the LDS in use */>
 __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t *__restrict__ tb, uint64_t *keys,
                                               uint32_t *cnt, uint32_t lane, uint32_t *__restrict__ sa_rows,
                                               uint8_t *__restrict__ bw, uint32_t *__restrict__ samples,
@@ -1424,7 +1452,7 @@ __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t 
   for (int m = 0; m < E; ++m) {
     const uint32_t b = at[m] & 0xFFFFu;
     const uint32_t s0 = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
-    keys[valid(m) ? s0 + (at[m] >> 16) : kWaveDummyKey] = r[m];
+    keys[valid(m) ? s0 + (at[m] >> 16) : DUMMY] = r[m];
     at[m] = s0;
   }
   wave_sync();
@@ -1442,7 +1470,7 @@ __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t 
   }
   wave_sync();
 #pragma unroll
-  for (int m = 0; m < E; ++m) keys[valid(m) ? at[m] + rank[m] : kWaveDummyKey] = r[m];
+  for (int m = 0; m < E; ++m) keys[valid(m) ? at[m] + rank[m] : DUMMY] = r[m];
   wave_sync();
   // sorted.  Row j = lane + 64 i: its neighbour j - 1 is the lane before (lane 63 of the round before)
   bool any_equal = false;
@@ -1473,7 +1501,8 @@ __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t 
   return 1;
 }
 
-// One leaf, by the wave that calls it (every lane); keys / cnt: the wave's own LDS.
+// One leaf of up to MAXROWS rows, by the wave that calls it (every lane); keys / cnt: the wave's own LDS.
+template <uint32_t MAXROWS>
 __device__ __forceinline__ void
 wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *keys, uint32_t *cnt,
           const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA, const uint32_t *__restrict__ bufB,
@@ -1481,8 +1510,9 @@ wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *key
           uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
           uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
           uint32_t *__restrict__ deferred) {
-  constexpr int E = kWavePer;
-  static_assert(E == 12 && kWaveBuckets / 2 == 4 * 64, "twelve rows, four counter words a lane");
+  constexpr int E = MAXROWS / 64;  // rows a lane owns, at most
+  constexpr uint32_t DUMMY = wave_dummy_key(MAXROWS);
+  static_assert((E == 12 || E == 16) && kWaveBuckets / 2 == 4 * 64, "twelve or sixteen rows, four counter words a lane");
   WaveLeaf L;
   L.leaf = leaf;
   L.size = __builtin_amdgcn_readfirstlane(lf.size);
@@ -1493,7 +1523,7 @@ wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *key
   L.src = srcid == kSrcA ? bufA : srcid == kSrcB ? bufB : nullptr;
   L.srckey = srcid == kSrcA ? keyA : keyB;
   const uint32_t size = L.size, start = L.start, depth = L.depth, keybases = L.keybases;
-  if (size > kWaveLeafMax) return;  // on the list of the workgroup-wide sort
+  if (size > MAXROWS) return;  // on another sort's list
   if (size == 1) {
     if (lane == 0) {
       const uint64_t w = leaf_fetch(tb, L.src, L.srckey, start, depth);
@@ -1507,9 +1537,10 @@ wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *key
     return;
   }
   int how;
-  if (size <= 256) how = wave_leaf_sort<4>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
-  else if (size <= 512) how = wave_leaf_sort<8>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
-  else how = wave_leaf_sort<12>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  if (MAXROWS > kWaveLeafMax) how = wave_leaf_sort<E, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);  // listed: all of a size
+  else if (size <= 256) how = wave_leaf_sort<4, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  else if (size <= 512) how = wave_leaf_sort<8, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  else how = wave_leaf_sort<12, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
   if (how == 0) {
     if (lane == 0) deferred[atomicAdd(&ctr->ndeferred, 1u)] = leaf;
     return;
@@ -1522,9 +1553,9 @@ wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *key
   // Blocked: lane l owns rows [l per, l per + per)
   uint32_t *settled = cnt;  // bit j: row j is ordered against row j-1 (the counters are done with)
   wave_sync();
-  if (lane < kWaveLeafMax / 32) settled[lane] = 0;
+  if (lane < MAXROWS / 32) settled[lane] = 0;
   wave_sync();
-  const uint32_t per = (size + 63u) / 64u;  // 1 .. kWavePer
+  const uint32_t per = (size + 63u) / 64u;  // 1 .. E
   const uint32_t j0 = lane * per;
   uint64_t w[E + 2];  // the lane's rows and one neighbour on each side: w[1 + k] is row j0 + k
   // short runs of equal keys: the lane that owns the first row of a run orders the
@@ -1634,15 +1665,35 @@ k_leaf_sort_wave(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ b
                  uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
                  uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
                  uint32_t first_leaf, uint32_t *__restrict__ deferred) {
-  __shared__ uint64_t keys_all[kWaveGroup][kWaveKeySlots];
+  __shared__ uint64_t keys_all[kWaveGroup][wave_key_slots(kWaveLeafMax)];
   __shared__ uint32_t cnt_all[kWaveGroup][kWaveCntWords];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t leaf = first_leaf + blockIdx.x * kWaveGroup + wv;
   // the grid may be sized by a guess made before the host knew the number of leaves
   if (leaf >= ctr->nleaves) return;
-  wave_leaf(leaf, leaves[leaf], lane, keys_all[wv], cnt_all[wv], tb, bufA, bufB, keyA, keyB, n, sa_rows, ghead, bw,
-            leaf_ties, samples, ctr, deferred);
+  wave_leaf<kWaveLeafMax>(leaf, leaves[leaf], lane, keys_all[wv], cnt_all[wv], tb, bufA, bufB, keyA, keyB, n, sa_rows,
+                          ghead, bw, leaf_ties, samples, ctr, deferred);
+}
+
+// The same for the listed leaves of kWaveLeafMax + 1 .. kWaveLeafMid rows (single children just too
+// large for the sort above): sixteen rows a lane and the LDS for them, four waves to a SIMD.
+__global__ void __launch_bounds__(64 * kWaveGroup) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_leaf_sort_wave_mid(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
+                     const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
+                     const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
+                     uint32_t *__restrict__ sa_rows, uint32_t *__restrict__ ghead, uint8_t *__restrict__ bw,
+                     uint8_t *__restrict__ leaf_ties, uint32_t *__restrict__ samples, Counters *__restrict__ ctr,
+                     const uint32_t *__restrict__ list, uint32_t *__restrict__ deferred) {
+  __shared__ uint64_t keys_all[kWaveGroup][wave_key_slots(kWaveLeafMid)];
+  __shared__ uint32_t cnt_all[kWaveGroup][kWaveCntWords];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t at = blockIdx.x * kWaveGroup + wv;
+  if (at >= ctr->nmid) return;
+  const uint32_t leaf = list[at];
+  wave_leaf<kWaveLeafMid>(leaf, leaves[leaf], lane, keys_all[wv], cnt_all[wv], tb, bufA, bufB, keyA, keyB, n, sa_rows,
+                          ghead, bw, leaf_ties, samples, ctr, deferred);
 }
 
 // Before prefix doubling: every row of a leaf that found no ties is its own group.
@@ -2572,7 +2623,7 @@ static int sa_doubling_groups(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint3
 // ---- driver -------------------------------------------------------------------
 
 struct Layout {
-  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, bigleaves, deferred, ctr, scanws, range, end;
+  size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, bigleaves, midleaves, deferred, ctr, scanws, range, end;
   uint64_t nwords;
   uint32_t seg_cap, leaf_cap;
 };
@@ -2602,6 +2653,7 @@ static Layout layout_for(uint32_t n) {
   L.leaves = take((size_t)L.leaf_cap * sizeof(Leaf));
   L.leaf_ties = take((size_t)L.leaf_cap);
   L.bigleaves = take((size_t)L.leaf_cap * 4);
+  L.midleaves = take((size_t)L.leaf_cap * 4);
   L.deferred = take((size_t)L.leaf_cap * 4);
   L.ctr = take(sizeof(Counters));
   L.scanws = take(scan_workspace_bytes(L.seg_cap + 1));
@@ -2661,6 +2713,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   Leaf *leaves = reinterpret_cast<Leaf *>(ws + L.leaves);
   uint8_t *leaf_ties = ws + L.leaf_ties;
   uint32_t *bigleaves = reinterpret_cast<uint32_t *>(ws + L.bigleaves);
+  uint32_t *midleaves = reinterpret_cast<uint32_t *>(ws + L.midleaves);
   uint32_t *deferred = reinterpret_cast<uint32_t *>(ws + L.deferred);
   Counters *ctr = reinterpret_cast<Counters *>(ws + L.ctr);
   void *scanws = ws + L.scanws;
@@ -2680,17 +2733,21 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
 
   uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
   int cur = 0;
-  uint32_t nleaves_host = 0, nbig_host = 0;
+  uint32_t nleaves_host = 0, nbig_host = 0, nmid_host = 0;
   if (n <= kLeafMax) {
     const Leaf whole = {0, n, 0, leaf_src_word(kSrcImplicit, kLeafKeyBases)};
     BWT_HIP(hipMemcpyAsync(leaves, &whole, sizeof whole, hipMemcpyHostToDevice, s));
     const uint32_t one = 1;
     BWT_HIP(hipMemcpyAsync(&ctr->nleaves, &one, 4, hipMemcpyHostToDevice, s));
     nleaves_host = 1;
-    if (n > kWaveLeafMax) {
+    if (n > kWaveLeafMid) {
       BWT_HIP(hipMemsetAsync(bigleaves, 0, 4, s));  // leaf 0
       BWT_HIP(hipMemcpyAsync(&ctr->nbig, &one, 4, hipMemcpyHostToDevice, s));
       nbig_host = 1;
+    } else if (n > kWaveLeafMax) {
+      BWT_HIP(hipMemsetAsync(midleaves, 0, 4, s));
+      BWT_HIP(hipMemcpyAsync(&ctr->nmid, &one, 4, hipMemcpyHostToDevice, s));
+      nmid_host = 1;
     }
   } else {
     const Seg whole = {0, n};
@@ -2779,7 +2836,8 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     }
     BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
-               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0, bigleaves);
+               L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0, bigleaves,
+               midleaves);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, n, dst,
                  dstkey, ctr, counts, leafmask, dlo, dhi);
@@ -2822,6 +2880,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     nsegs = h_ctr.nnext;
     nleaves_host = h_ctr.nleaves;
     nbig_host = h_ctr.nbig;
+    nmid_host = h_ctr.nmid;
     exact = true;
   }
   if (!exact) return set_error(kErrInternal, "SA build: level count not read back");
@@ -2832,6 +2891,10 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     BWT_LAUNCH("sa_leaf_sort", k_leaf_sort_wave, dim3((unsigned)div_up(nleaves_host - leaves_sorted, kWaveGroup)),
                dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples,
                ctr, leaves_sorted, deferred);
+  if (nmid_host)
+    BWT_LAUNCH("sa_leaf_sort_mid", k_leaf_sort_wave_mid, dim3((unsigned)div_up(nmid_host, kWaveGroup)),
+               dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples,
+               ctr, midleaves, deferred);
   if (nbig_host)
     BWT_LAUNCH("sa_leaf_sort_big", k_leaf_sort, dim3(nbig_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
                leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, bigleaves, 0u);
