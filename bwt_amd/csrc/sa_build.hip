@@ -1358,9 +1358,9 @@ struct WaveLeaf {
 // been written.  size in (64 (E - 4), 64 E].
 template <int E, uint32_t DUMMY /* wave_dummy_key of the LDS in use */>
 __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t *__restrict__ tb, uint64_t *keys,
-                                              uint32_t *cnt, uint32_t lane, uint32_t *__restrict__ sa_rows,
-                                              uint8_t *__restrict__ bw, uint32_t *__restrict__ samples,
-                                              Counters *__restrict__ ctr) {
+                                              uint32_t *cnt, uint32_t lane, uint32_t n,
+                                              uint32_t *__restrict__ sa_rows, uint8_t *__restrict__ bw,
+                                              uint32_t *__restrict__ samples, Counters *__restrict__ ctr) {
   const uint32_t size = L.size, start = L.start;
   uint64_t r[E];
   bool ok[4];  // whether the lane's last four slots are rows of the leaf; the others always are
@@ -1473,7 +1473,8 @@ __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t 
   for (int m = 0; m < E; ++m) keys[valid(m) ? at[m] + rank[m] : DUMMY] = r[m];
   wave_sync();
   // sorted.  Row j = lane + 64 i: its neighbour j - 1 is the lane before (lane 63 of the round before)
-  bool any_equal = false;
+  uint64_t tied[E];  // per round, the lanes whose row has the key of the row before it (the same in every lane)
+  uint64_t any_tied = 0, longer = 0, carry = 0;
   uint32_t before = 0xFFFFFFFFu;  // key of row 64 i - 1; no key has 32 bits
 #pragma unroll
   for (int i = 0; i < E; ++i) {
@@ -1482,10 +1483,39 @@ __device__ __forceinline__ int wave_leaf_sort(const WaveLeaf &L, const uint32_t 
     const uint32_t k = word_key(r[i]);
     const uint32_t up = __shfl_up(k, 1, 64);
     const uint32_t prev = lane ? up : before;
-    any_equal = any_equal || (j < size && prev == k);
+    tied[i] = __ballot(j < size && prev == k);
+    any_tied |= tied[i];
+    longer |= tied[i] & ((tied[i] << 1) | carry);  // the row before is tied to its own neighbour as well
+    carry = tied[i] >> 63;
     before = __shfl(k, 63, 64);
   }
-  if (__ballot(any_equal)) return 2;
+  if (any_tied) {
+    if (longer) return 2;  // a run of three or more equal keys
+    // Pairs only (a text of 3 x 10^9 bases: a few in every leaf).  The lane of a pair's
+    // second row compares the two suffixes beyond the key and swaps the words in LDS.
+    bool undecided = false;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      if (!tied[i]) continue;
+      if ((tied[i] >> lane) & 1u) {
+        const uint32_t j = lane + 64u * (uint32_t)i;
+        const uint64_t pw = keys[j - 1];
+        const int c = deep_cmp(tb, n, word_id(r[i]), word_id(pw), L.depth + L.keybases);
+        undecided = undecided || c == 0;
+        if (c < 0) {
+          keys[j - 1] = r[i];
+          keys[j] = pw;
+        }
+      }
+    }
+    if (__ballot(undecided)) return 2;  // equal for 512 bases more: the tie groups' business
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const uint32_t j = lane + 64u * (uint32_t)i;
+      r[i] = (i < E - 4 || j < size) ? keys[j] : ~0ull;
+    }
+  }
   // every row is its own group
 #pragma unroll
   for (int i = 0; i < E; ++i) {
@@ -1537,10 +1567,10 @@ wave_leaf(const uint32_t leaf, const Leaf lf, const uint32_t lane, uint64_t *key
     return;
   }
   int how;
-  if (MAXROWS > kWaveLeafMax) how = wave_leaf_sort<E, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);  // listed: all of a size
-  else if (size <= 256) how = wave_leaf_sort<4, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
-  else if (size <= 512) how = wave_leaf_sort<8, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
-  else how = wave_leaf_sort<12, DUMMY>(L, tb, keys, cnt, lane, sa_rows, bw, samples, ctr);
+  if (MAXROWS > kWaveLeafMax) how = wave_leaf_sort<E, DUMMY>(L, tb, keys, cnt, lane, n, sa_rows, bw, samples, ctr);  // listed: all of a size
+  else if (size <= 256) how = wave_leaf_sort<4, DUMMY>(L, tb, keys, cnt, lane, n, sa_rows, bw, samples, ctr);
+  else if (size <= 512) how = wave_leaf_sort<8, DUMMY>(L, tb, keys, cnt, lane, n, sa_rows, bw, samples, ctr);
+  else how = wave_leaf_sort<12, DUMMY>(L, tb, keys, cnt, lane, n, sa_rows, bw, samples, ctr);
   if (how == 0) {
     if (lane == 0) deferred[atomicAdd(&ctr->ndeferred, 1u)] = leaf;
     return;
