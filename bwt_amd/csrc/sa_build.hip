@@ -1154,7 +1154,38 @@ leaf_sort_block(const uint32_t leaf, const uint32_t *__restrict__ tb, const uint
   }
   // equal keys are rare (none in most leaves of a random text): only then are
   // runs settled by deeper comparison, in LDS, and the window read again
-  const bool ties = __syncthreads_or(any_equal);  // also: every thread has read its window
+  bool ties = __syncthreads_or(any_equal);  // also: every thread has read its window
+  if (ties) {
+    // Mostly pairs (a text of 250 Mbp sorted by 19 bases: one or two in every leaf): the
+    // thread of a pair's second row compares the two suffixes beyond the key and swaps
+    // the words in LDS.  A run of three or an undecided pair leaves it to the code below.
+    bool longer = false;
+#pragma unroll
+    for (uint32_t k = 0; k < kLeafPer; ++k) {
+      const uint32_t j = j0 + k;
+      longer = longer || (k < per && j > 0 && j + 1 < size && word_key(w[k]) == word_key(w[k + 1]) &&
+                          word_key(w[k + 2]) == word_key(w[k + 1]));
+    }
+    if (!__syncthreads_or(longer)) {
+      bool undecided = false;
+#pragma unroll
+      for (uint32_t k = 0; k < kLeafPer; ++k) {
+        const uint32_t j = j0 + k;
+        if (k < per && j > 0 && j < size && word_key(w[k]) == word_key(w[k + 1])) {
+          const int c = deep_cmp(tb, n, word_id(w[k + 1]), word_id(w[k]), depth + keybases);
+          undecided = undecided || c == 0;
+          if (c < 0) {
+            keys[pad(j - 1)] = w[k + 1];
+            keys[pad(j)] = w[k];
+          }
+        }
+      }
+      if (!__syncthreads_or(undecided)) {
+        load_window();
+        ties = false;
+      }
+    }
+  }
   uint64_t outv[kLeafPer];
   if (ties) {
     // short runs of equal keys: the thread that owns the first row of a run
