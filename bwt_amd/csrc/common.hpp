@@ -284,7 +284,17 @@ void pinned_release_idle();
 // index.hip
 // `readback`: 8 words of pinned host memory for C[] to land in, or null (the copy
 // into pageable memory then waits for the stream by itself).  Waits for `s`.
-int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback = nullptr);
+// A few words a kernel at the end of a build copies to pinned host memory for the
+// caller (each as a copy of its own is a stream operation of some microseconds).
+struct HostWords {
+  uint32_t *dst = nullptr;
+  const uint32_t *src = nullptr;
+  uint32_t words = 0;
+};
+// readback: 16 words of pinned host memory that kernels can write, or null; C[] is
+// then stored there by the scan itself, and `more` (two entries, or null) with it.
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback = nullptr,
+                             const HostWords *more = nullptr);
 int index_build_kmer_table(bwtgpu_index *ix, hipStream_t s);  // after endloc and C[] are known
 // Makes the search-only arrays an index still lacks (see bwtgpu_index); safe to
 // call from several threads, returns at once when there is nothing to do, and
@@ -311,6 +321,10 @@ struct SaExtras {
   // samples[i]), or null; out: whether all of them were written
   uint32_t *samples = nullptr;
   bool samples_done = false;
+  // in: room for the text in little-endian words (bwtgpu_index::d_text2, n/16 + 4 words), or
+  // null; out: whether the pass that re-deals the text for the sort filled it in
+  uint32_t *text2 = nullptr;
+  bool text2_done = false;
   // in: 16 words of pinned host memory, or null.  With it a whole-text build
   // does not wait to learn whether the leaf sort left rows tied: it hands out
   // the by-products as if none were, queues the copy of its counters into
@@ -318,10 +332,17 @@ struct SaExtras {
   // same stream and calls sa_build_settle after its next synchronisation.
   uint32_t *readback = nullptr;
   bool pending = false;
+  // in: with `pending`, the caller copies the sixteen counter words from later.ctr to
+  // `readback` itself, in a kernel of its own, before that synchronisation
+  bool caller_copies_counters = false;
   struct {  // what sa_build_settle needs of the workspace
     uint32_t *d_sa = nullptr, *ghead = nullptr, *flags = nullptr;
     void *leaves = nullptr, *leaf_ties = nullptr, *ctr = nullptr;
     uint32_t n = 0, nleaves = 0;
+    // the arguments of the sort of leaves the one-wave sort put off (see sa_build_settle)
+    const uint32_t *tb = nullptr, *bufB = nullptr, *keyA = nullptr, *keyB = nullptr, *deferred = nullptr;
+    uint32_t *bufA = nullptr, *samples = nullptr;
+    uint8_t *bw = nullptr;
   } later;
 };
 // 0: no row was left tied, the by-products stand.  1: tied rows were sorted by

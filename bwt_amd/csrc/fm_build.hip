@@ -396,6 +396,13 @@ static uint32_t *readback_acquire(int *slot) {
       (void)hipGetLastError();
       return nullptr;
     }
+    // kernels store into it through the same address
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess || d != p) {
+      (void)hipGetLastError();
+      (void)hipHostFree(p);
+      return nullptr;
+    }
     g_readback_page = static_cast<uint32_t *>(p);
   }
   if (!g_readback_free) return nullptr;
@@ -492,8 +499,9 @@ static void alloc_kept_arrays(bwtgpu_index *ix, uint32_t n) {
 // ix->d_sa when the index keeps them); bw, when not null, is the BWT symbol of
 // rows 1..n and *d_endloc then already holds the $ row.
 static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const uint32_t *d_sa,
-                      const uint8_t *bw, uint32_t *d_endloc, bool have_samples, hipStream_t s,
-                      uint32_t *readback = nullptr /* 16 pinned words, or null */) {
+                      const uint8_t *bw, uint32_t *d_endloc, bool have_samples, bool have_text2, hipStream_t s,
+                      uint32_t *readback = nullptr /* 16 pinned words, or null */,
+                      const HostWords *counters = nullptr /* with readback: copied along, or null */) {
   const uint64_t rows = (uint64_t)n + 1, t2words = (uint64_t)n / 16 + 4;
   if (bw) {
     BWT_LAUNCH("emit_planes_rows", k_emit_planes_rows,
@@ -509,14 +517,18 @@ static int emit_index(bwtgpu_index *ix, const uint8_t *d_text, uint32_t n, const
   const uint64_t ns = ((uint64_t)n >> kDevSampleShift) + 1;
   if (!have_samples)  // else the leaf sort dropped them as it wrote the rows
     BWT_LAUNCH("sample_sa", k_sample_sa, dim3((unsigned)div_up(ns, 256)), dim3(256), 0, s, d_sa, ns, ix->d_idxs);
-  if (ix->d_sa)  // the caller's text may be gone by the time a search wants the records
+  if (ix->d_sa && !have_text2)  // the caller's text may be gone by the time a search wants the records
     BWT_LAUNCH("make_text2", k_make_text2, dim3((unsigned)div_up(t2words, 256)), dim3(256), 0, s, d_text, n,
                t2words, ix->d_text2);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(readback ? readback + 8 : &ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && !readback) e = hipMemcpyAsync(&ix->endloc, d_endloc, 4, hipMemcpyDeviceToHost, s);
   if (e != hipSuccess) return set_error(kErrHip, "BWT emission: %s", hipGetErrorString(e));
-  BWT_TRY(index_finish_from_planes(ix, s, readback));  // synchronises the stream
+  HostWords more[2];
+  more[0].dst = readback ? readback + 8 : nullptr;
+  more[0].src = d_endloc;
+  more[0].words = 1;
+  if (counters) more[1] = *counters;
+  BWT_TRY(index_finish_from_planes(ix, s, readback, more));  // synchronises the stream
   if (readback) ix->endloc = readback[8];
   if (ix->endloc > n) return set_error(kErrInternal, "no suffix-array row holds suffix 0");
   // what make_fmi produces is complete; the search-only arrays wait for the first search
@@ -575,18 +587,32 @@ static int build_from_device_text(const uint8_t *d_text, uint32_t n, hipStream_t
   extras.samples = ix->d_idxs;
   uint32_t *readback = g_cache.readback;  // words 0..15: the sort's counters; 16..31: emit_index
   extras.readback = readback;
+  extras.text2 = ix->d_sa ? ix->d_text2 : nullptr;
+  extras.caller_copies_counters = readback != nullptr;
   rc = sa_build_impl(d_text, n, d_sa, g_cache.ws, ws_bytes, s, &extras);
   if (rc == kOk) {
-    if (extras.bw) (void)hipMemcpyAsync(d_endloc, extras.endloc, 4, hipMemcpyDeviceToDevice, s);
     const bool assumed = extras.pending;  // ... that the leaf sort left no rows tied
-    rc = emit_index(ix, d_text, n, d_sa, extras.bw, d_endloc, extras.samples_done, s,
-                    readback ? readback + 16 : nullptr);
+    const bool have_text2 = extras.text2_done;
+    HostWords counters;
+    if (assumed && readback) {
+      counters.dst = readback;
+      counters.src = static_cast<const uint32_t *>(extras.later.ctr);
+      counters.words = 16;
+    }
+    // the $ row: where the leaf sort left it, when it wrote the BWT symbols too
+    uint32_t *endloc_at = extras.bw ? const_cast<uint32_t *>(extras.endloc) : d_endloc;
+    rc = emit_index(ix, d_text, n, d_sa, extras.bw, endloc_at, extras.samples_done, have_text2, s,
+                    readback ? readback + 16 : nullptr, assumed && readback ? &counters : nullptr);
     if (assumed) {
-      if (rc != kOk) (void)hipStreamSynchronize(s);  // emit_index waits only when all went well
+      if (rc != kOk) {  // emit_index waits, and its last kernels bring the counters along, only when all went well
+        (void)hipStreamSynchronize(s);
+        if (readback) (void)hipMemcpy(readback, extras.later.ctr, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      }
       const int settled = sa_build_settle(&extras, s);
       if (settled < 0) rc = settled;
       else if (settled > 0)  // it had: the rows have changed, emit again from the final suffix array
-        rc = emit_index(ix, d_text, n, d_sa, nullptr, d_endloc, false, s, readback ? readback + 16 : nullptr);
+        rc = emit_index(ix, d_text, n, d_sa, nullptr, d_endloc, false, have_text2, s,
+                        readback ? readback + 16 : nullptr);
     }
   }
   if (rc != kOk) {
@@ -714,7 +740,7 @@ bwtgpu_index *bwtgpu_index_build_from_sa(const uint8_t *d_text, uint32_t n, cons
     rc = set_error(kErrHip, "suffix array copy failed");
   if (rc == kOk && d_bw && hipMemcpyAsync(d_endloc, &endloc, 4, hipMemcpyHostToDevice, s) != hipSuccess)
     rc = set_error(kErrHip, "endloc upload failed");
-  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, false, s);
+  if (rc == kOk) rc = emit_index(ix, d_text, n, ix->d_sa ? ix->d_sa : d_sa, d_bw, d_endloc, false, false, s);
   if (rc != kOk) {
     bwtgpu_index_free(ix);
     return nullptr;

@@ -97,7 +97,8 @@ k_rank_tile_reduce(const IndexBlock *__restrict__ blocks, uint64_t nblocks, uint
 // Pass 2: one workgroup turns tile totals into exclusive tile prefixes with
 // C[c] folded in, and publishes C[0..4] (seqindex.c:183-187).
 __global__ void __launch_bounds__(1024)
-k_rank_scan_tiles(uint4 *__restrict__ tile_sums, uint32_t ntiles, uint32_t *__restrict__ d_C) {
+k_rank_scan_tiles(uint4 *__restrict__ tile_sums, uint32_t ntiles, uint32_t *__restrict__ d_C,
+                  uint32_t *__restrict__ host_C /* pinned, or null */, const HostWords more0, const HostWords more1) {
   __shared__ uint32_t s[4][1024];
   __shared__ uint32_t carry[4];
   __shared__ uint32_t Cs[5];
@@ -121,7 +122,11 @@ k_rank_scan_tiles(uint4 *__restrict__ tile_sums, uint32_t ntiles, uint32_t *__re
     Cs[0] = 1;
     for (int q = 0; q < 4; ++q) Cs[q + 1] = Cs[q] + s[q][0];
     for (int q = 0; q < 5; ++q) d_C[q] = Cs[q];
+    if (host_C)
+      for (int q = 0; q < 5; ++q) host_C[q] = Cs[q];
   }
+  if ((uint32_t)t < more0.words) more0.dst[t] = more0.src[t];
+  if ((uint32_t)t < more1.words) more1.dst[t] = more1.src[t];
   __syncthreads();
   // second sweep: chunked exclusive scan with a running carry
   for (uint32_t base = 0; base < ntiles; base += 1024) {
@@ -645,7 +650,7 @@ int index_alloc(bwtgpu_index **out, uint32_t n) {
 }
 
 // Planes of every block are in place; computes occ[] and C[].
-int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback) {
+int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback, const HostWords *more) {
   const uint64_t nb = ix->nblocks;
   const uint32_t ntiles = (uint32_t)div_up(nb, kTileBlocks);
   uint4 *d_tiles = nullptr;
@@ -654,14 +659,15 @@ int index_finish_from_planes(bwtgpu_index *ix, hipStream_t s, uint32_t *readback
   d_C = reinterpret_cast<uint32_t *>(d_tiles + ntiles);
   BWT_LAUNCH("rank_tile_reduce", k_rank_tile_reduce, dim3(ntiles), dim3(kTileThreads), 0, s,
              ix->d_blocks, nb, ix->n, d_tiles);
-  BWT_LAUNCH("rank_scan_tiles", k_rank_scan_tiles, dim3(1), dim3(1024), 0, s, d_tiles, ntiles, d_C);
+  const HostWords none;
+  BWT_LAUNCH("rank_scan_tiles", k_rank_scan_tiles, dim3(1), dim3(1024), 0, s, d_tiles, ntiles, d_C, readback,
+             readback && more ? more[0] : none, readback && more ? more[1] : none);
   BWT_LAUNCH("rank_apply", k_rank_apply, dim3(ntiles), dim3(kTileThreads), 0, s, ix->d_blocks, nb,
              ix->n, d_tiles);
   BWT_LAUNCH("rank_build_sym", k_build_sym, dim3((unsigned)div_up(ix->nsym, 256)), dim3(256), 0, s,
              ix->d_blocks, nb, ix->n, ix->d_sym, ix->nsym);
   hipError_t e = hipGetLastError();
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(readback ? readback : ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && !readback) e = hipMemcpyAsync(ix->C, d_C, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) (void)hipDeviceSynchronize();
   else if (readback)

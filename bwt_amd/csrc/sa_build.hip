@@ -70,11 +70,44 @@ struct Counters {
 
 // ---- text -------------------------------------------------------------
 
+// What a build sets before its first level, done by the kernel that re-deals the
+// text (each as a copy or a fill of its own was eight stream operations of a few
+// microseconds before the first kernel that does work).
+struct BuildInit {
+  Counters *ctr;         // zeroed; min_depth = none yet
+  uint32_t *row0;        // row 0 of the suffix array = n (histsortcomp.c:165), or null
+  uint32_t *sample0;     // the sample of row 0, or null
+  uint32_t *ghead0;      // tie-group head of row 0
+  Seg *seg0;             // level 0's one segment, the whole text; null when the text is a single leaf
+  uint32_t *tile_first;  // ... and where its tiles begin
+  uint32_t *zero;        // counters of the first two levels
+  uint32_t zero_words;
+  uint32_t *text2;       // the text in little-endian 16-base words, one word of zeros in front (what the
+  uint64_t t2words;      // position records are made from), or null
+};
+
 // Big-endian 16-base words of the text: base i at bits 31-2*(i&15) of word
 // i>>4, zeros from base n on, kTextPadWords words of zeros after the end.
 __global__ void k_prepare_text(const uint8_t *__restrict__ text, uint32_t n, uint64_t nwords,
-                               uint32_t *__restrict__ tb) {
+                               uint32_t *__restrict__ tb, const BuildInit init) {
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint64_t i = w; i < init.zero_words; i += (uint64_t)gridDim.x * blockDim.x) init.zero[i] = 0;
+  if (w == 0) {
+    Counters c = {};
+    c.min_depth = 0xFFFFFFFFu;
+    if (init.seg0) {
+      // what k_begin_level_small would make of a list of this one segment
+      *init.seg0 = Seg{0, n};
+      init.tile_first[0] = 0;
+      c.ncur = 1;
+      c.total_tiles = (n + kPartTile - 1) / kPartTile;
+    }
+    *init.ctr = c;
+    if (init.row0) *init.row0 = n;
+    if (init.sample0) *init.sample0 = n;
+    *init.ghead0 = 0;
+    if (init.text2) init.text2[0] = 0;
+  }
   if (w >= nwords) return;
   const uint64_t nbytes = (uint64_t)n / 4 + 1;
   uint32_t v = 0;
@@ -89,7 +122,13 @@ __global__ void k_prepare_text(const uint8_t *__restrict__ text, uint32_t n, uin
   const uint64_t first = 16 * w;
   const uint32_t valid = first >= n ? 0u : (n - first >= 16 ? 16u : (uint32_t)(n - first));
   const uint32_t mask = valid == 16 ? ~0u : (valid == 0 ? 0u : ~((1u << (32 - 2 * valid)) - 1u));
-  tb[w] = v & mask;
+  v &= mask;
+  tb[w] = v;
+  if (init.text2 && w + 1 < init.t2words) {
+    // the same bases, the first one in the lowest two bits
+    const uint32_t x = __builtin_bitreverse32(v);
+    init.text2[w + 1] = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  }
 }
 
 // 16 bases starting at position p, first base in the top bits
@@ -2683,6 +2722,43 @@ static int sa_doubling_groups(uint32_t *d_sa, uint32_t *ghead, uint32_t n, uint3
 
 // ---- driver -------------------------------------------------------------------
 
+// A second stream per building thread and device, and the event `s` waits on for it.
+// Not freed: a thread may end after the runtime has shut down.
+struct LeafSide {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+};
+static thread_local LeafSide g_leaf_side;
+
+static hipStream_t leaf_side_stream(hipStream_t s) {
+  static const bool off = [] {
+    const char *e = getenv("BWT_MI355X_LEAF_STREAMS");
+    return e && e[0] == '0';
+  }();
+  if (off || timing().enabled) return s;  // timed launch by launch: one after the other
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return s;
+  LeafSide &g = g_leaf_side;
+  if (g.device != dev) {
+    g = LeafSide{};
+    if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g.done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      g = LeafSide{};
+      return s;
+    }
+    g.device = dev;
+  }
+  return g.stream;
+}
+
+static int leaf_side_join(hipStream_t s) {
+  BWT_HIP(hipEventRecord(g_leaf_side.done, g_leaf_side.stream));
+  BWT_HIP(hipStreamWaitEvent(s, g_leaf_side.done, 0));
+  return kOk;
+}
+
 struct Layout {
   size_t tb, bufB, keyA, keyB, bw, ghead, segs0, segs1, counts, leafmask, tile_first, leaves, leaf_ties, bigleaves, midleaves, deferred, ctr, scanws, range, end;
   uint64_t nwords;
@@ -2747,6 +2823,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     extras->bw = nullptr;
     extras->endloc = nullptr;
     extras->samples_done = false;
+    extras->text2_done = false;
     extras->pending = false;
   }
   if (!d_text || !d_sa || !d_ws) return set_error(kErrArg, "null argument");
@@ -2781,16 +2858,25 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
   const size_t scanws_bytes = scan_workspace_bytes(L.seg_cap + 1);
   g_stats = SaStats{};
 
+  // Level 0 counts into the words behind the 256 x 256 that level 1 can use, so both are zeroed here
+  static_assert(kTextPadWords >= 3, "the text in words reaches as far as the little-endian copy");
+  uint32_t *counts0 = counts + 256 * 256;
+  BuildInit init = {};
+  init.ctr = ctr;
+  init.row0 = range ? nullptr : d_sa;
+  init.sample0 = samples;  // SA[0] = n is row 0's sample
+  init.ghead0 = ghead;
+  init.seg0 = n > kLeafMax ? segs[0] : nullptr;
+  init.tile_first = tile_first;
+  init.zero = counts;
+  init.zero_words = n > kLeafMax ? 256 * 256 + 8 * 256 : 0;
+  init.text2 = (extras && !range) ? extras->text2 : nullptr;
+  init.t2words = (uint64_t)n / 16 + 4;
   BWT_LAUNCH("sa_prepare_text", k_prepare_text, dim3((unsigned)div_up(L.nwords, 256)), dim3(256), 0, s,
-             d_text, n, L.nwords, tb);
+             d_text, n, L.nwords, tb, init);
+  if (init.text2) extras->text2_done = true;
   Counters h_ctr = {};
   h_ctr.min_depth = 0xFFFFFFFFu;
-  BWT_HIP(hipMemcpyAsync(ctr, &h_ctr, sizeof h_ctr, hipMemcpyHostToDevice, s));
-  // row 0 of the suffix array is the end-of-text suffix (histsortcomp.c:165)
-  const uint32_t row0[1] = {n};
-  if (!range) BWT_HIP(hipMemcpyAsync(d_sa, row0, 4, hipMemcpyHostToDevice, s));
-  if (samples) BWT_HIP(hipMemcpyAsync(samples, row0, 4, hipMemcpyHostToDevice, s));  // SA[0] = n is row 0's sample
-  BWT_HIP(hipMemsetAsync(ghead, 0, 4, s));
 
   uint32_t nsegs = 0, depth = 0, src_id = kSrcImplicit;
   int cur = 0;
@@ -2811,11 +2897,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       nmid_host = 1;
     }
   } else {
-    const Seg whole = {0, n};
-    BWT_HIP(hipMemcpyAsync(segs[0], &whole, sizeof whole, hipMemcpyHostToDevice, s));
-    const uint32_t one = 1;
-    BWT_HIP(hipMemcpyAsync(&ctr->nnext, &one, 4, hipMemcpyHostToDevice, s));
-    nsegs = 1;
+    nsegs = 1;  // the whole text: k_prepare_text has listed it
   }
   // A text without long repeats is through after the first level whose buckets
   // hold kLeafMax suffixes on average.  Up to that level the host does not wait
@@ -2845,7 +2927,10 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     uint32_t *dst = dst_id == kSrcA ? bufA : bufB;
     uint32_t *dstkey = dst_id == kSrcA ? keyA : keyB;
     // this level's segments and where the tiles of each begin
-    if (nsegs <= 1024) {
+    const bool implicit = src_id == kSrcImplicit;  // level 0: one segment, counts per eighth of its tiles
+    if (implicit) {
+      // set by k_prepare_text
+    } else if (nsegs <= 1024) {
       BWT_LAUNCH("sa_begin_level", k_begin_level_small, dim3(1), dim3(1024), 0, s, ctr, nsegs, segs[cur], tile_first);
     } else {
       BWT_LAUNCH("sa_begin_level", k_begin_level, dim3(1), dim3(64), 0, s, ctr, nsegs);
@@ -2854,24 +2939,24 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       BWT_TRY(device_scan_u32(ScanOp::kAddExclusive, tile_first, tile_first, nsegs, &ctr->total_tiles,
                               scanws, scanws_bytes, s));
     }
-    const bool implicit = src_id == kSrcImplicit;  // level 0: one segment, counts per eighth of its tiles
-    BWT_HIP(hipMemsetAsync(counts, 0, (size_t)(implicit ? 8 : nsegs) * 256 * 4, s));
+    uint32_t *lcounts = implicit ? counts0 : counts;
+    if (levels > 1) BWT_HIP(hipMemsetAsync(counts, 0, (size_t)nsegs * 256 * 4, s));  // else zeroed by k_prepare_text
     const unsigned tile_bound = (unsigned)(((uint64_t)n / kPartTile + nsegs + 1 + 7) / 8 * 8);  // eighths, see locate_tile
     const unsigned hist_groups = (tile_bound + kHistTilesPerGroup - 1) / kHistTilesPerGroup;
     const uint32_t *srckey = src_id == kSrcA ? keyA : keyB;
     unsigned long long *d_range = reinterpret_cast<unsigned long long *>(ws + L.range);
     if (src_id == kSrcImplicit) {
       if (range) BWT_HIP(hipMemsetAsync(d_range, 0, kRangeBytes + 16, s));
-      BWT_LAUNCH("sa_part_hist_l0", k_part_hist0, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, n, ctr, counts, dlo,
+      BWT_LAUNCH("sa_part_hist_l0", k_part_hist0, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, n, ctr, lcounts, dlo,
                  dhi, range ? d_range : (unsigned long long *)nullptr);
     } else if (levels == 1) {
       // level 0 stored words that start with this level's four bases
       BWT_LAUNCH("sa_part_hist", k_part_hist<3>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, depth, ctr, lcounts);
     } else {
       // the word stored by the previous level holds this level's four bases in its second byte
       BWT_LAUNCH("sa_part_hist", k_part_hist<2>, dim3(hist_groups), dim3(kPartThreads), 0, s, tb, src,
-                 srckey, segs[cur], tile_first, depth, ctr, counts);
+                 srckey, segs[cur], tile_first, depth, ctr, lcounts);
     }
     // Without a gather a suffix that ends in a leaf keeps bases [depth, reach) as
     // its sort key, and one that goes on needs the next level's digit, bases
@@ -2882,7 +2967,7 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
       // rows of other shards leave the picture here
       uint64_t *d_out = reinterpret_cast<uint64_t *>(d_range) + kRangeSlots * kRangeSlotStride;
       uint64_t h_out[2] = {0, 0};
-      BWT_LAUNCH("sa_restrict_level0", k_restrict_level0, dim3(1), dim3(256), 0, s, counts, dlo, dhi, d_range, d_out);
+      BWT_LAUNCH("sa_restrict_level0", k_restrict_level0, dim3(1), dim3(256), 0, s, lcounts, dlo, dhi, d_range, d_out);
       BWT_HIP(hipMemcpyAsync(h_out, d_out, sizeof h_out, hipMemcpyDeviceToHost, s));
       BWT_HIP(hipStreamSynchronize(s));
       range->row_begin = 1 + h_out[0];
@@ -2895,18 +2980,18 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
         return kOk;
       }
     }
-    BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], counts, depth,
+    BWT_LAUNCH("sa_part_classify", k_part_classify, dim3(nsegs), dim3(256), 0, s, segs[cur], lcounts, depth,
                leaf_src_word(dst_id, leaf_keybases < kLeafKeyBases ? leaf_keybases : kLeafKeyBases), segs[cur ^ 1],
                L.seg_cap, leaves, L.leaf_cap, leafmask, ctr, implicit ? 1 : 0, bigleaves,
                midleaves);
     if (src_id == kSrcImplicit) {
       BWT_LAUNCH("sa_part_scatter_l0", k_part_scatter0, dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, n, dst,
-                 dstkey, ctr, counts, leafmask, dlo, dhi);
+                 dstkey, ctr, lcounts, leafmask, dlo, dhi);
       reach = kDigitBases + kLeafKeyBases;  // suffixes that go on carry bases 4..18
     } else {
       BWT_LAUNCH(levels == 1 ? "sa_part_scatter_l1" : "sa_part_scatter_l2+", k_part_scatter,
                  dim3(tile_bound), dim3(kScat1Threads), 0, s, tb, src, srckey, dst, dstkey, segs[cur], tile_first,
-                 depth, ctr, counts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
+                 depth, ctr, lcounts, gather_all ? 1 : 0, levels == 1 ? 1 : 0);
       if (gather_all) reach = depth + kLeafKeyBases;
     }
     BWT_CHECK_LAUNCH();
@@ -2952,14 +3037,24 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     BWT_LAUNCH("sa_leaf_sort", k_leaf_sort_wave, dim3((unsigned)div_up(nleaves_host - leaves_sorted, kWaveGroup)),
                dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples,
                ctr, leaves_sorted, deferred);
-  if (nmid_host)
-    BWT_LAUNCH("sa_leaf_sort_mid", k_leaf_sort_wave_mid, dim3((unsigned)div_up(nmid_host, kWaveGroup)),
-               dim3(64 * kWaveGroup), 0, s, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples,
-               ctr, midleaves, deferred);
-  if (nbig_host)
-    BWT_LAUNCH("sa_leaf_sort_big", k_leaf_sort, dim3(nbig_host), dim3(kLeafThreads), 0, s, tb, bufA, bufB, keyA, keyB,
-               leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, bigleaves, 0u);
-  if (nleaves_host) {
+  {
+    // The listed leaves are other rows than the one-wave sort's: on a stream of their own they
+    // run beside it.  Everything before the one-wave sort has finished (the host has read the
+    // counts), so that stream waits for nothing; `s` waits for it.
+    hipStream_t ls = (nmid_host || nbig_host) ? leaf_side_stream(s) : s;
+    if (nmid_host)
+      BWT_LAUNCH("sa_leaf_sort_mid", k_leaf_sort_wave_mid, dim3((unsigned)div_up(nmid_host, kWaveGroup)),
+                 dim3(64 * kWaveGroup), 0, ls, tb, bufA, bufB, keyA, keyB, leaves, n, bufA, ghead, bw, leaf_ties,
+                 samples, ctr, midleaves, deferred);
+    if (nbig_host)
+      BWT_LAUNCH("sa_leaf_sort_big", k_leaf_sort, dim3(nbig_host), dim3(kLeafThreads), 0, ls, tb, bufA, bufB, keyA,
+                 keyB, leaves, n, bufA, ghead, bw, leaf_ties, samples, ctr, bigleaves, 0u);
+    if (ls != s) BWT_TRY(leaf_side_join(s));
+  }
+  // A whole-text build whose caller reads the counters at its own synchronisation learns there
+  // whether any leaf was put off (sa_build_settle): none in a text without repeats
+  const bool settle_later = extras && extras->readback && !range && !nsegs;
+  if (nleaves_host && !settle_later) {
     // what the waves left to whole workgroups when they met it (lopsided keys): the count is on the device,
     // zero for a text without repeats
     const unsigned groups = nleaves_host < 512u ? nleaves_host : 512u;
@@ -2979,10 +3074,11 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
                shortl);
   }
   BWT_CHECK_LAUNCH();
-  if (extras && extras->readback && !range && !nsegs) {
+  if (settle_later) {
     // the usual case has no tied rows: let the caller get on with it (see SaExtras)
     static_assert(sizeof(Counters) <= 16 * sizeof(uint32_t), "readback words");
-    BWT_HIP(hipMemcpyAsync(extras->readback, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+    if (!extras->caller_copies_counters)
+      BWT_HIP(hipMemcpyAsync(extras->readback, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
     extras->bw = bw;
     extras->endloc = &ctr->endloc;
     extras->samples_done = samples != nullptr;
@@ -2995,6 +3091,14 @@ int sa_build_core(const uint8_t *d_text, uint32_t n, uint32_t *d_sa, SaRange *ra
     extras->later.ctr = ctr;
     extras->later.n = n;
     extras->later.nleaves = nleaves_host;
+    extras->later.tb = tb;
+    extras->later.bufA = bufA;
+    extras->later.bufB = bufB;
+    extras->later.keyA = keyA;
+    extras->later.keyB = keyB;
+    extras->later.deferred = deferred;
+    extras->later.samples = samples;
+    extras->later.bw = bw;
     return kOk;
   }
   BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
@@ -3029,17 +3133,30 @@ int sa_build_settle(SaExtras *extras, hipStream_t s) {
   extras->pending = false;
   Counters h_ctr;
   std::memcpy(&h_ctr, extras->readback, sizeof h_ctr);
+  const auto &L = extras->later;
+  Counters *ctr = static_cast<Counters *>(L.ctr);
+  const bool put_off = h_ctr.ndeferred != 0;
+  if (put_off) {
+    // leaves whose keys were too lopsided for one wave (repeats): a workgroup each, now
+    const unsigned groups = L.nleaves < 512u ? L.nleaves : 512u;
+    BWT_LAUNCH("sa_leaf_sort_deferred", k_leaf_sort_deferred, dim3(groups), dim3(kLeafThreads), 0, s, L.tb, L.bufA,
+               L.bufB, L.keyA, L.keyB, static_cast<const Leaf *>(L.leaves), L.n, L.bufA, L.ghead, L.bw,
+               static_cast<uint8_t *>(L.leaf_ties), L.samples, ctr, L.deferred);
+    BWT_CHECK_LAUNCH();
+    BWT_HIP(hipMemcpyAsync(&h_ctr, ctr, sizeof h_ctr, hipMemcpyDeviceToHost, s));
+    BWT_HIP(hipStreamSynchronize(s));
+  }
   g_stats.v[2] = h_ctr.unresolved;
-  if (!h_ctr.unresolved) return 0;
+  if (!h_ctr.unresolved && !put_off) return 0;
   extras->bw = nullptr;
   extras->endloc = nullptr;
   extras->samples_done = false;
-  if (extras->later.nleaves)
-    BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(extras->later.nleaves), dim3(256), 0, s,
-               static_cast<const Leaf *>(extras->later.leaves), static_cast<const uint8_t *>(extras->later.leaf_ties),
-               extras->later.ghead);
-  BWT_TRY(sa_finish_ties(extras->later.d_sa, extras->later.ghead, extras->later.n, h_ctr.min_depth,
-                         extras->later.flags, static_cast<Counters *>(extras->later.ctr), s));
+  if (h_ctr.unresolved) {
+    if (L.nleaves)
+      BWT_LAUNCH("sa_ghead_identity", k_ghead_identity, dim3(L.nleaves), dim3(256), 0, s,
+                 static_cast<const Leaf *>(L.leaves), static_cast<const uint8_t *>(L.leaf_ties), L.ghead);
+    BWT_TRY(sa_finish_ties(L.d_sa, L.ghead, L.n, h_ctr.min_depth, L.flags, ctr, s));
+  }
   BWT_HIP(hipStreamSynchronize(s));
   return 1;
 }
