@@ -53,7 +53,7 @@ k_emit_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa,
 // Same, when the suffix-array build left the BWT symbol of every row behind
 // (bw[r-1] for row r >= 1): a streaming pass, no gather.  Row 0 is the $ suffix,
 // preceded by the last base of the text.
-constexpr int kPlanesPerWave = 8;  // blocks one wave emits: its loads are issued together
+constexpr int kPlanesPerWave = 16;  // blocks one wave emits: its loads are issued together
 
 __global__ void __launch_bounds__(256)
 k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__ bw, uint32_t n,
@@ -73,14 +73,19 @@ k_emit_planes_rows(const uint8_t *__restrict__ text, const uint8_t *__restrict__
       base[k] = row ? bw[row - 1] : text_base(text, (uint64_t)n - 1);
     }
   }
+  uint64_t mylo = 0, myhi = 0;  // lane k keeps block b0 + k: one store instruction for all of them
 #pragma unroll
   for (int k = 0; k < kPlanesPerWave; ++k) {
     const uint64_t lo = __ballot(base[k] & 1u);
     const uint64_t hi = __ballot(base[k] & 2u);
-    if (lane == 0 && b0 + k < nblocks) {
-      blocks[b0 + k].lo = lo;
-      blocks[b0 + k].hi = hi;
+    if (lane == (uint32_t)k) {
+      mylo = lo;
+      myhi = hi;
     }
+  }
+  if (lane < (uint32_t)kPlanesPerWave && b0 + lane < nblocks) {
+    blocks[b0 + lane].lo = mylo;
+    blocks[b0 + lane].hi = myhi;
   }
 }
 
