@@ -1778,7 +1778,7 @@ k_leaf_sort_wave(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ b
 
 // The same for the listed leaves of kWaveLeafMax + 1 .. kWaveLeafMid rows (single children just too
 // large for the sort above): sixteen rows a lane and the LDS for them, four waves to a SIMD.
-__global__ void __launch_bounds__(64 * kWaveGroup) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(64 * kWaveGroup) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_leaf_sort_wave_mid(const uint32_t *__restrict__ tb, const uint32_t *__restrict__ bufA,
                      const uint32_t *__restrict__ bufB, const uint32_t *__restrict__ keyA,
                      const uint32_t *__restrict__ keyB, const Leaf *__restrict__ leaves, uint32_t n,
