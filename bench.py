@@ -845,6 +845,24 @@ def main():
                           "same_output": bool(torch.equal(sp4, sp) and torch.equal(ep4, ep) and torch.equal(lr4, lr)),
                           "index_bytes": ixl.device_bytes}
             ixl.close()
+            # the third form: loaded and kept lean (rank blocks, sampled rows, a one-word table of the
+            # k-mer intervals' starts; no suffix array, text or position records)
+            ixn = G.index_from_parts(bwt_h, n, ix.endloc, idxs_h, lean=True)
+            ixn.prepare_search()
+            ixn.search(d_reads, m, R, want_locrow=True, out=(sp4, ep4, lr4))
+            torch.cuda.synchronize()
+            lean_steps = min(side_steps, 10)
+            t4 = time.perf_counter()
+            for _ in range(lean_steps):
+                ixn.search(d_reads, m, R, want_locrow=True, out=(sp4, ep4, lr4))
+            torch.cuda.synchronize()
+            ln = time.perf_counter() - t4
+            loaded_leg["kept_lean"] = {
+                "what": "the same parts loaded with lean=True: rank blocks, sampled rows and a one-word k-mer table",
+                "value": R * lean_steps / ln, "unit": "reads/s", "ms_per_step": ln / lean_steps * 1e3,
+                "same_output": bool(torch.equal(sp4, sp) and torch.equal(ep4, ep) and torch.equal(lr4, lr)),
+                "index_bytes": ixn.device_bytes}
+            ixn.close()
             del sp4, ep4, lr4
         except Exception as e:  # noqa: BLE001 - the headline does not depend on this
             loaded_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
