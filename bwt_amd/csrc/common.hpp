@@ -176,7 +176,15 @@ constexpr uint32_t kPosRecordMaxN = 0xFFFFFF00u;
 __host__ __device__ inline uint64_t pos_record_place(uint64_t b) {
   return (b & ~7ull) | ((b & 3ull) << 1) | ((b >> 2) & 1ull);
 }
-inline uint64_t pos_record_count(uint32_t n) {
+// Wide records, for texts whose records outgrow the last-level cache anyway (where reads
+// are mostly longer than 53 bases as well): eight positions and the 128 bases from the
+// record's first position on, so one line serves a read of up to 121 bases that starts
+// in it, and every further 112 bases (14 records: the offset stays) one more.  Fourteen
+// guard records; records in their natural order.  8 bytes a base instead of 5.33.
+constexpr uint32_t kWidePosPerRecord = 8;
+constexpr uint32_t kWideGuardRecords = 14;
+inline uint64_t pos_record_count(uint32_t n, bool wide) {
+  if (wide) return (uint64_t)n / kWidePosPerRecord + kWideGuardRecords + 2;
   return ((uint64_t)n / kPosPerRecord + kPosGuardRecords + 2 + 7) / 8 * 8;  // whole groups
 }
 
@@ -202,7 +210,8 @@ struct bwtgpu_index {
   // search finishes by comparing the read with the text once its interval is a
   // single row, and locate is one lookup.
   uint32_t *d_sa = nullptr;     // n+1 rows
-  uint32_t *d_isa = nullptr;    // position -> row, as pos_record_count(n) PosRecords (with their text)
+  uint32_t *d_isa = nullptr;    // position -> row, as pos_record_count(n, rec_wide) PosRecords (with their text)
+  bool rec_wide = false;        // the records are the wide kind (set before d_isa is published)
   uint32_t *d_text2 = nullptr;  // [0] guard, [1 + w] = bases 16w..16w+15, base k at bits 2k
   // Optional: where the SA interval of every string of kmer_k bases starts, i.e.
   // the state of a backward search after its first kmer_k steps, indexed by the

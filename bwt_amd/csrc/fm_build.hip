@@ -110,9 +110,9 @@ k_check_planes(const uint8_t *__restrict__ text, const uint32_t *__restrict__ sa
   if (lane == 0 && (blocks[b].lo != lo || blocks[b].hi != hi)) *mismatch = 1u;
 }
 
-__global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t *__restrict__ isa) {
+__global__ void k_inverse_sa(const uint32_t *__restrict__ sa, uint64_t rows, uint32_t *__restrict__ isa, int wide) {
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < rows) isa[isa_slot(sa[j])] = (uint32_t)j;
+  if (j < rows) isa[isa_slot(sa[j], wide != 0)] = (uint32_t)j;
 }
 
 // Inverse of a suffix array, in two steps so that the 4-byte scatter stays
@@ -237,14 +237,14 @@ k_isa_deal(const uint32_t *__restrict__ sa, const uint64_t *__restrict__ in, uin
 // Infinity Cache, which all XCDs share, and are then filled one after the other
 // by all of them.
 __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
-                           uint32_t *__restrict__ isa, int xcd_local) {
+                           uint32_t *__restrict__ isa, int xcd_local, int wide) {
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   const uint64_t chunk =
       xcd_local ? (uint64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : (uint64_t)blockIdx.x;
   const uint64_t j = chunk * blockDim.x + threadIdx.x;
   if (j >= rows) return;
   const uint64_t pr = pairs[j];
-  isa[isa_slot((uint32_t)pr)] = (uint32_t)(pr >> 32);
+  isa[isa_slot((uint32_t)pr, wide != 0)] = (uint32_t)(pr >> 32);
 }
 
 // The text part of every position record: the 64 bases from the record's first
@@ -253,9 +253,21 @@ __global__ void k_isa_fill(const uint64_t *__restrict__ pairs, uint64_t rows,
 // them fetch the text as well cost more than this pass; and after them: run
 // first, its lines were still in the caches when the pairs were being dealt.)
 __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, uint64_t nrec,
-                              uint32_t *__restrict__ recs) {
+                              uint32_t *__restrict__ recs, int wide) {
   const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nrec) return;
+  if (wide) {  // 128 bases behind the eight rows
+    const int64_t first = ((int64_t)b - kWideGuardRecords) * kWidePosPerRecord;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t at = first + 16 * k;
+      w[k] = (at <= -16 || at >= (int64_t)n) ? 0u : text16(text2, at);
+    }
+    reinterpret_cast<uint4 *>(recs)[b * 4 + 2] = make_uint4(w[0], w[1], w[2], w[3]);
+    reinterpret_cast<uint4 *>(recs)[b * 4 + 3] = make_uint4(w[4], w[5], w[6], w[7]);
+    return;
+  }
   const int64_t first = ((int64_t)b - kPosGuardRecords) * kPosPerRecord;
   uint32_t w[4];
 #pragma unroll
@@ -270,17 +282,19 @@ __global__ void k_record_text(const uint32_t *__restrict__ text2, uint32_t n, ui
 // text from d_text2.  scratch (may be null): 8 (n+1) + 2048 bytes that nothing
 // else is using.
 static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t *d_text2, uint32_t *d_isa,
-                                void *scratch, hipStream_t s) {
+                                bool wide, void *scratch, hipStream_t s) {
   const uint64_t rows = (uint64_t)n + 1;
+  const uint64_t rec_bytes = wide ? 8 : 6;  // of records a position, rounded up
   auto record_text = [&]() {
-    BWT_LAUNCH("record_text", k_record_text, dim3((unsigned)div_up(pos_record_count(n), 256)), dim3(256), 0, s,
-               d_text2, n, pos_record_count(n), d_isa);
+    BWT_LAUNCH("record_text", k_record_text, dim3((unsigned)div_up(pos_record_count(n, wide), 256)), dim3(256), 0, s,
+               d_text2, n, pos_record_count(n, wide), d_isa, wide ? 1 : 0);
   };
   // small arrays sit in L2 whatever the order of the stores
   const char *env = getenv("BWT_MI355X_ISA_TWO_STEP");  // for tests on small texts: 1 = one level, 2 = two
   const bool force = env != nullptr, force2 = env && env[0] == '2';
   if (!scratch || (rows <= (1ull << 22) && !force)) {
-    BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa);
+    BWT_LAUNCH("inverse_sa", k_inverse_sa, dim3((unsigned)div_up(rows, 256)), dim3(256), 0, s, d_sa, rows, d_isa,
+               wide ? 1 : 0);
     record_text();
     return kOk;
   }
@@ -295,7 +309,7 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t
   uint32_t window_shift = shift;
   uint64_t *pairs2 = nullptr;
   unsigned long long *d_cur2 = nullptr;
-  if (((6ull << shift) > (2ull << 20) || force2) && shift >= 13) {  // tiles of 2^13 pairs must not straddle bins
+  if (((rec_bytes << shift) > (2ull << 20) || force2) && shift >= 13) {  // tiles of 2^13 pairs must not straddle bins
     // windows beyond an L2: split each bin once more, if there is room for a second pair buffer
     if (pool_alloc(&pairs2, rows * 8) == hipSuccess && pool_alloc(&d_cur2, 65536 * 8) == hipSuccess) {
       const uint32_t shift2 = shift - 8;
@@ -308,9 +322,9 @@ static int inverse_suffix_array(const uint32_t *d_sa, uint32_t n, const uint32_t
       (void)hipGetLastError();
     }
   }
-  const int xcd_local = (6ull << window_shift) <= (2ull << 20);  // a window of records within half an L2
+  const int xcd_local = (rec_bytes << window_shift) <= (2ull << 20);  // a window of records within half an L2
   BWT_LAUNCH("isa_fill", k_isa_fill, dim3((unsigned)(div_up(div_up(rows, 256), 8) * 8)), dim3(256), 0, s, filled,
-             rows, d_isa, xcd_local);
+             rows, d_isa, xcd_local, wide ? 1 : 0);
   record_text();
   hipError_t e = hipGetLastError();
   if (pairs2 || d_cur2) {
@@ -548,9 +562,17 @@ int index_build_records(bwtgpu_index *ix, hipStream_t s) {
   if (!ix->d_sa || !ix->d_text2 || ix->d_isa) return kOk;
   const uint32_t n = ix->n;
   uint32_t *isa = nullptr;  // the index gets it when every record is written
-  if (pool_alloc(&isa, pos_record_count(n) * sizeof(PosRecord)) != hipSuccess) {
+  // Wide records (see kWidePosPerRecord) once the twelve-position kind is several times the
+  // last-level cache anyway; BWT_MI355X_WIDE_RECORDS=0 / 1 says otherwise (tests)
+  bool wide = n >= (1u << 27);
+  if (const char *e = getenv("BWT_MI355X_WIDE_RECORDS")) wide = e[0] == '1';
+  if (pool_alloc(&isa, pos_record_count(n, wide) * sizeof(PosRecord)) != hipSuccess) {
     (void)hipGetLastError();
-    return kOk;
+    wide = false;
+    if (pool_alloc(&isa, pos_record_count(n, wide) * sizeof(PosRecord)) != hipSuccess) {
+      (void)hipGetLastError();
+      return kOk;
+    }
   }
   // scratch for the two-step scatter: the calling thread's idle build workspace
   // when it is large enough (the build that has just returned left it), else a
@@ -565,12 +587,16 @@ int index_build_records(bwtgpu_index *ix, hipStream_t s) {
     if (pool_alloc(&own, ((size_t)n + 1) * 8 + 2048) == hipSuccess) scratch = own;
     else (void)hipGetLastError();  // the one-step scatter needs none
   }
-  int rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, isa, scratch, s);
+  int rc = inverse_suffix_array(ix->d_sa, n, ix->d_text2, isa, wide, scratch, s);
   if (rc == kOk && hipStreamSynchronize(s) != hipSuccess) rc = set_error(kErrHip, "position records failed");
   if (rc != kOk) (void)hipDeviceSynchronize();
   pool_free(own);
-  if (rc != kOk) pool_free(isa);
-  else publish(ix->d_isa, isa);
+  if (rc != kOk) {
+    pool_free(isa);
+  } else {
+    ix->rec_wide = wide;
+    publish(ix->d_isa, isa);
+  }
   return rc;
 }
 

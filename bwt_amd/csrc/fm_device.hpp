@@ -22,11 +22,13 @@ struct IndexView {
   uint64_t nsym;
   uint32_t n;
   uint32_t endloc;
+  uint32_t rec_wide;      // the position records are the wide kind
 };
 
 inline IndexView view_of(const bwtgpu_index *ix) {
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, ix->d_sa,   ix->d_isa, ix->d_text2,
-                   ix->d_kmer,   ix->d_kmer2, ix->d_kmer4, ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc};
+                   ix->d_kmer,   ix->d_kmer2, ix->d_kmer4, ix->kmer_k, ix->kmer_w, ix->kmer_sizebits, ix->nsym, ix->n, ix->endloc,
+                   ix->rec_wide ? 1u : 0u};
 }
 
 // The view for entry points that do not wait for the search-only arrays: all of
@@ -38,7 +40,7 @@ inline IndexView view_published(const bwtgpu_index *ix) {
   if (ix->search_ready.load(std::memory_order_acquire)) return view_of(ix);
   const uint32_t *sa = __atomic_load_n(&ix->d_sa, __ATOMIC_ACQUIRE);
   return IndexView{ix->d_blocks, ix->d_sym, ix->d_idxs, sa, nullptr, nullptr, nullptr, nullptr, nullptr,
-                   0u, 1u, 0u, ix->nsym, ix->n, ix->endloc};
+                   0u, 1u, 0u, ix->nsym, ix->n, ix->endloc, 0u};
 }
 
 __device__ __forceinline__ uint64_t low_mask(uint32_t r) {
@@ -161,13 +163,14 @@ __device__ __forceinline__ uint32_t div12(uint32_t p, uint32_t &rem) {
 }
 
 // word index of position p's row in the array of PosRecords
-__device__ __forceinline__ uint64_t isa_slot(uint32_t p) {
+__device__ __forceinline__ uint64_t isa_slot(uint32_t p, bool wide) {
+  if (wide) return ((uint64_t)(p >> 3) + kWideGuardRecords) * 16u + (p & 7u);
   uint32_t o;
   const uint32_t b = div12(p, o);
   return pos_record_place((uint64_t)b + kPosGuardRecords) * 16u + o;
 }
 
-__device__ __forceinline__ uint32_t isa_at(const IndexView &v, uint32_t p) { return v.isa[isa_slot(p)]; }
+__device__ __forceinline__ uint32_t isa_at(const IndexView &v, uint32_t p) { return v.isa[isa_slot(p, v.rec_wide != 0)]; }
 
 // j / 96 and j % 96 for a 32-bit j
 __device__ __forceinline__ uint32_t div96(uint32_t j, uint32_t &rem) {

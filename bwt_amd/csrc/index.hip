@@ -790,7 +790,7 @@ size_t bwtgpu_index_device_bytes(const bwtgpu_index *ix) {
   return ix->nblocks * sizeof(IndexBlock) + 4 * ix->nsym * sizeof(SymBlock) +
          (((size_t)ix->n >> kDevSampleShift) + 1) * 4 +
          (ix->d_sa ? ((size_t)ix->n + 1) * 4 + ((size_t)ix->n / 16 + 4) * 4 : 0) +
-         (ix->d_isa ? pos_record_count(ix->n) * sizeof(PosRecord) : 0) +
+         (ix->d_isa ? pos_record_count(ix->n, ix->rec_wide) * sizeof(PosRecord) : 0) +
          (ix->d_kmer ? (((uint64_t)ix->kmer_w << (2 * ix->kmer_k)) + 2) * sizeof(uint32_t) + kKmerMaxGaps * sizeof(uint2)
                      : 0) +
          (ix->d_kmer2 ? (sizeof(uint2) << (2 * (ix->kmer_k - 2))) : 0) +

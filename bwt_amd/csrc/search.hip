@@ -94,7 +94,8 @@ struct CTable {
 // words and searches from there, so the packed form never goes to HBM.  Used
 // when bytes and words of a workgroup's reads (256, 128 or 64 of them) fit
 // kFusedLdsBytes.
-template <bool VERIFY, bool COUNT, bool FUSED>
+// WIDE: the position records are the wide kind (kWidePosPerRecord).
+template <bool VERIFY, bool COUNT, bool FUSED, bool WIDE = false>
 __global__ void __launch_bounds__(256)
 k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8_t *__restrict__ pats,
          uint64_t stride, uint64_t R, uint32_t m, uint32_t *__restrict__ d_sp,
@@ -255,32 +256,47 @@ k_search(IndexView v, CTable C, const uint32_t *__restrict__ packed, const uint8
     if (COUNT) n_ent += table_pos != 0xFFFFFFFFu ? 1 : 2;  // the SA entry unless the table had it, and the one ISA entry read below
     const uint32_t jmin = pos < rem ? rem - pos : 0u;  // bases below jmin would lie before the text
     // the highest read base j in [jmin, rem) that differs from text[pos - rem + j];
-    // the record of position pos - rem + 48 g holds the text for read words 3g..3g+2
+    // the record of position pos - rem + GB g holds the text for read words GW g .. GW g + GW - 1
+    // (GB = 48 bases and GW = 3 words; 112 and 7 for wide records)
+    constexpr uint32_t GW = WIDE ? 7u : 3u, GB = 16u * GW;
     int jbad = -1;
     uint32_t row_all = 0;  // ISA[pos - rem]: in the record read last
     bool before_text = false;
-    for (int g = (int)((rem - 1) / 48u); g >= 0 && jbad < 0 && !before_text; --g) {
-      if (48u * g + 48u <= jmin) break;
+    for (int g = (int)((rem - 1) / GB); g >= 0 && jbad < 0 && !before_text; --g) {
+      if (GB * g + GB <= jmin) break;
       uint32_t o;
-      const uint64_t b = pos_record_place(div12((pos + 48u) - (rem - 48u * g), o));  // guard records included
-      const uint4 tx = reinterpret_cast<const uint4 *>(v.isa)[b * 4u + 3u];
+      uint64_t b;  // guard records included: they hold GB positions
+      uint32_t tx[GW + 1];
+      if (WIDE) {
+        const uint32_t at0 = (pos + GB) - (rem - GB * g);
+        o = at0 & 7u;
+        b = at0 >> 3;
+        const uint4 ta = reinterpret_cast<const uint4 *>(v.isa)[b * 4u + 2u];
+        const uint4 tb = reinterpret_cast<const uint4 *>(v.isa)[b * 4u + 3u];
+        tx[0] = ta.x; tx[1] = ta.y; tx[2] = ta.z; tx[3] = ta.w;
+        tx[4] = tb.x; tx[5] = tb.y; tx[6] = tb.z; tx[GW] = tb.w;
+      } else {
+        b = pos_record_place(div12((pos + GB) - (rem - GB * g), o));
+        const uint4 ta = reinterpret_cast<const uint4 *>(v.isa)[b * 4u + 3u];
+        tx[0] = ta.x; tx[1] = ta.y; tx[2] = ta.z; tx[GW] = ta.w;
+      }
       if (g == 0 && jmin == 0) row_all = v.isa[b * 16u + o];
       if (COUNT) ++n_txt;
-      for (int wl = 2; wl >= 0 && jbad < 0; --wl) {
-        const uint32_t w = 3u * g + wl;
+#pragma unroll
+      for (int wl = (int)GW - 1; wl >= 0; --wl) {
+        if (jbad >= 0 || before_text) continue;
+        const uint32_t w = GW * g + wl;
         if (16u * w >= rem) continue;
         if (16u * w + 16u <= jmin) {
           before_text = true;
-          break;
+          continue;
         }
         const uint32_t lo = jmin > 16u * w ? jmin - 16u * w : 0u;
         const uint32_t hi = rem - 16u * w < 16u ? rem - 16u * w : 16u;
         const uint32_t rw = word_at(w);
         if (COUNT) ++n_pat;
-        const uint32_t at = o + 16u * wl, wi = at >> 4;  // 16 bases from base `at` of the record's 64
-        const uint32_t t_lo = wi == 0 ? tx.x : wi == 1 ? tx.y : tx.z;
-        const uint32_t t_hi = wi == 0 ? tx.y : wi == 1 ? tx.z : tx.w;
-        const uint32_t tw = (uint32_t)((((uint64_t)t_hi << 32) | t_lo) >> (2u * (at & 15u)));
+        // 16 bases from base o + 16 wl of the record's text: o < 16, so they start in word wl
+        const uint32_t tw = (uint32_t)((((uint64_t)tx[wl + 1] << 32) | tx[wl]) >> (2u * o));
         uint32_t d = rw ^ tw;
         d = (d | (d >> 1)) & 0x55555555u;
         const uint32_t keep = (hi == 16 ? ~0u : ((1u << (2 * hi)) - 1u)) & ~((1u << (2 * lo)) - 1u);
@@ -779,7 +795,10 @@ static int search_impl(const bwtgpu_index *ix, const IndexView &v, const uint8_t
   // Long reads get smaller workgroups so that they still fit.
   if (fused_nt) {
     const dim3 fgrid((unsigned)div_up(R, fused_nt)), fblock(fused_nt);
-    if (v.isa)
+    if (v.isa && v.rec_wide)
+      BWT_LAUNCH("fm_search", (k_search<true, false, true, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
+                 d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, fused_rounds);
+    else if (v.isa)
       BWT_LAUNCH("fm_search", (k_search<true, false, true>), fgrid, fblock, (size_t)fused_lds, s, v, C, packed,
                  d_pats, stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, fused_rounds);
     else
@@ -793,12 +812,18 @@ static int search_impl(const bwtgpu_index *ix, const IndexView &v, const uint8_t
              use_lds ? (size_t)align_up(span, 16) : 0, s, d_pats, m, stride, R, packed, use_lds);
   BWT_CHECK_LAUNCH();
   if (d_counters) {
-    if (v.isa)
+    if (v.isa && v.rec_wide)
+      BWT_LAUNCH("fm_search_counting", (k_search<true, true, false, true>), grid, block, 0, s, v, C, packed, d_pats,
+                 stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
+    else if (v.isa)
       BWT_LAUNCH("fm_search_counting", (k_search<true, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
     else
       BWT_LAUNCH("fm_search_counting", (k_search<false, true, false>), grid, block, 0, s, v, C, packed, d_pats,
                  stride, R, m, d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
+  } else if (v.isa && v.rec_wide) {
+    BWT_LAUNCH("fm_search", (k_search<true, false, false, true>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
+               d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
   } else if (v.isa) {
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, packed, d_pats, stride, R, m,
                d_sp, d_ep, d_locrow, d_pos, d_counters, R, (uint64_t)1, 1u);
@@ -826,7 +851,11 @@ static int search_packed_impl(const bwtgpu_index *ix, const uint32_t *d_words, u
   const IndexView v = view_of(ix);
   const dim3 grid((unsigned)div_up(R, 256)), block(256);
   const uint64_t words = (m + 15) / 16;
-  if (ix->d_isa)
+  if (ix->d_isa && v.rec_wide)
+    BWT_LAUNCH("fm_search", (k_search<true, false, false, true>), grid, block, 0, s, v, C, d_words,
+               (const uint8_t *)nullptr, (uint64_t)0, R, m, d_sp, d_ep, d_locrow, d_pos,
+               (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
+  else if (ix->d_isa)
     BWT_LAUNCH("fm_search", (k_search<true, false, false>), grid, block, 0, s, v, C, d_words, (const uint8_t *)nullptr,
                (uint64_t)0, R, m, d_sp, d_ep, d_locrow, d_pos, (unsigned long long *)nullptr, (uint64_t)1, words, 1u);
   else

@@ -192,13 +192,20 @@ def _check_search_locate(gpu, ix, d, m, R, sp, ep, pos, msg):
 
 @pytest.mark.parametrize("n,R,m,kind", [(13, 300, 20, "random"), (40, 600, 9, "random"), (777, 2000, 25, "random"),
                                         (100003, 20000, 50, "random"), (1000000, 20000, 100, "random"),
-                                        (200000, 10000, 64, "mutated-repeat"), (50000, 5000, 33, "tandem")],
+                                        (200000, 10000, 64, "mutated-repeat"), (50000, 5000, 33, "tandem"),
+                                        (300000, 6000, 130, "random"), (300000, 4000, 260, "random"),
+                                        (5000, 3000, 600, "random")],
                          ids=lambda v: str(v))
-def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R, m, kind):
+@pytest.mark.parametrize("records", ["twelve", "wide"])
+def test_search_with_kept_suffix_array_equals_rank_only_search(oracle, gpu, n, R, m, kind, records, monkeypatch):
     """An index built on the device keeps SA, ISA and the text and finishes a
     search from the text once one row is left; an index loaded from its stored
     parts has only the rank blocks.  Both must give loc_search's interval
-    (seqindex.c:280-309) and locate's row (seqindex.c:258-277) for every read."""
+    (seqindex.c:280-309) and locate's row (seqindex.c:258-277) for every read.
+    records: the position records of twelve positions and 64 bases (what a text of
+    this size gets) or the wide ones of eight positions and 128 bases (texts of
+    2^27 bases and more)."""
+    monkeypatch.setenv("BWT_MI355X_WIDE_RECORDS", "1" if records == "wide" else "0")
     if kind == "random":
         text = oracle.gen_genome(n, synth.GENOME_SEED + n)
     elif kind == "tandem":

@@ -85,6 +85,7 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
                 os.environ["BWT_MI355X_ISA_TWO_STEP"] = "12"[int(rng.integers(0, 2))]
             else:
                 os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
+            os.environ["BWT_MI355X_WIDE_RECORDS"] = "01"[int(rng.integers(0, 2))]  # position records of either kind
             t = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
             sa = G.sa_build(t, n)
             assert np.array_equal(G.to_numpy_u32(sa), sa_o), "SA"
@@ -195,10 +196,12 @@ def main(budget, seed0=1, nmax=300000, max_cases=None, quiet=False):
             full.close(); lean.close(); loaded.close()
         except AssertionError as e:
             raise AssertionError(f"MISMATCH {label} kmer_env={os.environ.get('BWT_MI355X_KMER')} "
-                                 f"sizebits_env={os.environ.get('BWT_MI355X_KMER_SIZEBITS')}: {e}") from e
+                                 f"sizebits_env={os.environ.get('BWT_MI355X_KMER_SIZEBITS')} "
+                                 f"wide_records={os.environ.get('BWT_MI355X_WIDE_RECORDS')}: {e}") from e
         finally:
             os.environ.pop("BWT_MI355X_KMER", None)
             os.environ.pop("BWT_MI355X_KMER_SIZEBITS", None)
+            os.environ.pop("BWT_MI355X_WIDE_RECORDS", None)
             os.environ.pop("BWT_MI355X_ISA_TWO_STEP", None)
         it += 1
         seed += 1
