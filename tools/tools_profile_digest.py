@@ -17,8 +17,8 @@ bench = os.path.join(root, "bench.json")
 if os.path.exists(bench):
     txt = open(bench).read().strip().splitlines()
     open(os.path.join(out, f"{tag}_bench.json"), "w").write(txt[-1] + "\n")
-want = {"fm_search": "k_search<true, false, true>", "fm_search_rank_only": "k_search<false, false, true>",
-        "fm_search_unfused": "k_search<true, false, false>", "isa_partition": "k_isa_deal<1>", "isa_partition2": "k_isa_deal<2>", "isa_fill": "k_isa_fill",
+want = {"fm_search": "k_search<true, false, true", "fm_search_rank_only": "k_search<false, false, true",
+        "fm_search_unfused": "k_search<true, false, false", "isa_partition": "k_isa_deal<1>", "isa_partition2": "k_isa_deal<2>", "isa_fill": "k_isa_fill",
         "pack_reads": "k_pack_reads", "leaf_sort": "k_leaf_sort", "part_scatter": "k_part_scatter",
         "part_hist": "k_part_hist", "inverse_sa": "k_inverse_sa", "kmer_level": "k_kmer_level",
         "locate_walk": "k_locate(", "locate_sa": "k_locate_sa"}
