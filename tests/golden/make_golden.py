@@ -75,7 +75,7 @@ def main():
     G = {"generator": "tests/golden/make_golden.py", "source": "oracle/_ref/libbwtref.so (unmodified reference)",
          "genome_seed": GENOME_SEED, "reads_seed": READS_SEED}
 
-    # 1. the 40-base text of the survey, in full
+    # 1. a 40-base text (every base, runs, a repeat), in full
     t = np.array([0x1B, 0xE4, 0x00, 0xFF, 0x6C, 0x1B, 0xE4, 0x93, 0x27, 0x4E, 0x00], np.uint8)
     sa = ref.histsort(t, 40)
     assert (sa == ref.csuff_arr(t, 40)).all()
@@ -140,8 +140,8 @@ def main():
     f = ref.make_fmi(text, n)
     G["threaded"] = {"n": n, "sa": sha(sa), **fmi_record(ref, f)}
 
-    # 5. build_index's packer: the reference binary's behaviour on ACGTTTT is
-    # recorded in the survey (len 7, C 1 5 6 7 8, endloc 4, idxs 7, bwt 03 18);
+    # 5. build_index's packer: what the reference's build_index makes of ACGTTTT
+    # is known (len 7, C 1 5 6 7 8, endloc 4, idxs 7, bwt 03 18);
     # here the same text packed as build_index.c:54-87 does it, then indexed
     packed = orc.pack_ascii(b"ACGTTTT")
     f = ref.make_fmi(packed, 7, sacak=True)
