@@ -191,7 +191,8 @@ int bwtgpu_index_kmer_table(const bwtgpu_index *ix, uint32_t *k, uint32_t *entry
 int bwtgpu_index_compact(bwtgpu_index *ix);
 /* A build or load returns as soon as what make_fmi produces (seqindex.c:161-189:
  * BWT, sampled rows, rank blocks, C[], the $ row) is in place; the arrays that
- * only speed searches up -- position records, k-mer table, 5.3 + about 4 bytes
+ * only speed searches up -- position records, k-mer table, 5.3 (8 for texts of
+ * 2^27 bases and more, whose records hold 128 bases each) + about 4 bytes
  * per base -- are made by the first bwtgpu_search / _mms / _search_reads /
  * _align_reads call on the index (once; concurrent first calls wait for each
  * other), so an index that is built only to be written to a file never pays
