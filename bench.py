@@ -471,7 +471,7 @@ def bench_c4(args, rank, world, dist, barrier, red_dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=["c2", "c4"], default="c2",
                     help="c2: 46 Mbp, 10 M x 50 bp per GPU (weak); c4: 3.1 Gbp, 100 M x 100 bp over all GPUs (strong)")
@@ -481,7 +481,7 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the tandem-repeat build leg (c2, one GPU)")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the 3.1 Gbp / 100 M x 100 bp leg of the default line (c2, one GPU)")
-    ap.add_argument("--c4-steps", type=int, default=20, help="timed steps of that leg")
+    ap.add_argument("--c4-steps", type=int, default=100, help="timed steps of that leg")
     ap.add_argument("--c5-steps", type=int, default=5, help="timed search steps on the tandem-repeat text")
     ap.add_argument("--build-reps", type=int, default=3)
     ap.add_argument("--cpu-reads", type=int, default=4_000_000)
